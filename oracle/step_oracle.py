@@ -1,0 +1,83 @@
+"""fp32 CPU restatement of the alternating G/D step.
+
+TEST INFRASTRUCTURE - see ``oracle/__init__.py``.
+
+Step ordering follows src/v2/training.py:176-211 ( == src/v1/gan.py:221-252 ):
+  D.zero_grad; D(real)->loss->backward; fake=G(noise); D(fake.detach())->loss->backward;
+  disc_optimizer.step(); G.zero_grad; D(fake)->loss(label=real)->backward; gen_optimizer.step().
+Optimizer: AdamW(lr, weight_decay=1e-3), default betas/eps (training.py:150-157).
+Loss: the reference's v2 criterion call raises; the executable loss is
+v1's BCE on sigmoid outputs with labels 1/0 and 1 for G (gan.py:16-20,227,238,250)
+== BCE-with-logits here ("ns").  "hinge" is the optional loss north_star names;
+it is not in the reference and is pinned only against torch.nn.functional.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Mapping, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .gen_oracle import GenDims, gen_forward
+from .vit_oracle import VitDims, vit_forward
+
+Tensor = torch.Tensor
+
+
+def d_loss_real(logits: Tensor, kind: str) -> Tensor:
+    if kind == "ns":
+        return F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    if kind == "hinge":
+        return F.relu(1.0 - logits).mean()
+    raise ValueError(kind)
+
+
+def d_loss_fake(logits: Tensor, kind: str) -> Tensor:
+    if kind == "ns":
+        return F.binary_cross_entropy_with_logits(logits, torch.zeros_like(logits))
+    if kind == "hinge":
+        return F.relu(1.0 + logits).mean()
+    raise ValueError(kind)
+
+
+def g_loss(logits: Tensor, kind: str) -> Tensor:
+    if kind == "ns":
+        return F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    if kind == "hinge":
+        return -logits.mean()
+    raise ValueError(kind)
+
+
+class GanStepOracle:
+    """Holds leaf tensors for D (v2 ViT) and G (v1 SLN/SIREN) and runs reference steps."""
+
+    def __init__(self, d_state: Mapping[str, Tensor], g_state: Mapping[str, Tensor],
+                 ddims: VitDims, gdims: GenDims, lr_d: float = 5e-4, lr_g: float = 5e-4,
+                 weight_decay: float = 1e-3, loss: str = "ns"):
+        self.ddims, self.gdims, self.loss = ddims, gdims, loss
+        self.d = {k: v.detach().clone().float().requires_grad_(True) for k, v in d_state.items()}
+        self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
+        self.opt_d = torch.optim.AdamW(list(self.d.values()), lr=lr_d, weight_decay=weight_decay)
+        self.opt_g = torch.optim.AdamW(list(self.g.values()), lr=lr_g, weight_decay=weight_decay)
+
+    def D(self, x: Tensor) -> Tensor:
+        return vit_forward(self.d, x, self.ddims)
+
+    def G(self, z: Tensor) -> Tensor:
+        return gen_forward(self.g, z, self.gdims)
+
+    def step(self, real: Tensor, z: Tensor) -> Dict[str, float]:
+        for p in self.d.values():
+            p.grad = None
+        loss_real = d_loss_real(self.D(real), self.loss)
+        loss_real.backward()
+        fake = self.G(z)
+        loss_fake = d_loss_fake(self.D(fake.detach()), self.loss)
+        loss_fake.backward()
+        self.opt_d.step()
+        for p in self.g.values():
+            p.grad = None
+        loss_g = g_loss(self.D(fake), self.loss)
+        loss_g.backward()
+        self.opt_g.step()
+        return {"d_real": float(loss_real), "d_fake": float(loss_fake), "g": float(loss_g)}
