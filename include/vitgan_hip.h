@@ -1,0 +1,163 @@
+/*
+ * vitgan_hip.h - C ABI of libvitgan_hip.so, the MI355X (gfx950) compute library under the
+ * ViTGAN nn.Module surface.
+ *
+ * The reference (krzkro4122/vit-gan) is pure Python on PyTorch ATen ops and has no FFI / operator
+ * plugin interface of its own; its boundary for the hot path is the nn.Module surface
+ * of src/v2/modules.py plus the step body of src/v2/training.py:170-211.  Each entry point below
+ * names the reference code whose ATen call sequence it replaces.  The Python side binds these with
+ * ctypes (vit-gan_amd/_lib.py); INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless it says "host";
+ *   - `bf16` tensors are passed as `void*` (2-byte IEEE bfloat16, row-major);
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host
+ *     synchronisation, no allocation), so callers may capture a sequence of calls in a hipGraph;
+ *   - return value: 0 on success, a positive hipError_t, or a negative argument-validation code
+ *     (-1 bad count, -2 bad size, -3 unsupported shape/alignment, -4 bad mode).  Nothing is
+ *     launched when the return value is negative.
+ *   - ownership: the caller owns all memory; the library keeps no state between calls.
+ */
+#ifndef VITGAN_HIP_H
+#define VITGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_ABI_VERSION 1
+int vg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Single operators (parity-tested one by one; tests/test_ops_gpu.py)
+ * ---------------------------------------------------------------------------------------- */
+
+/* nn.Linear forward (+ fused epilogue):  C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + res
+ * replaces F.linear / nn.GELU / residual add of src/v2/modules.py:128-139,161,179-182 and
+ * sin(30*Linear) of src/v1/siren.py:44-45.
+ * act: 0 none, 1 GELU(erf), 2 sin(act_scale*v), 3 tanh.  bias fp32 [N] or NULL; res bf16 [M,N]
+ * or NULL; pre_bf16 (bf16 [M,N]) / pre_f32 (fp32 [M,N]) receive the pre-activation or NULL. */
+int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* res, void* C,
+                  void* pre_bf16, float* pre_f32, int M, int N, int K, int act, float act_scale,
+                  void* stream);
+/* input gradient of nn.Linear:  dX[M,K] = dY[M,N] @ W[N,K]   (autograd of F.linear)
+ * mul_mode 0: none; 4: dX *= gelu'(Z) with Z bf16 [M,K]; 5: dX *= s*cos(s*Zf), Zf fp32 [M,K]. */
+int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode,
+                    const void* Z, const float* Zf, float act_scale, void* stream);
+/* weight gradient of nn.Linear:  dW[N,K] (+)= dY[M,N]^T @ X[M,K], computed as `splits` slices of M
+ * into fp32 slabs (slab_ws: splits*N*K floats) folded in a fixed order (deterministic). */
+int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, int M, int N, int K,
+                    int splits, int accumulate, void* stream);
+
+/* nn.LayerNorm forward/backward (src/v2/modules.py:168,172,225; eps 1e-5, biased variance).
+ * x,y bf16 [R,E] with row strides xs/ys (elements); mean/rstd fp32 [R]. E % 128 == 0, E <= 1024. */
+int vg_layernorm_fwd(const void* x, long long xs, const float* gamma, const float* beta, void* y,
+                     long long ys, float* mean, float* rstd, int R, int E, float eps, void* stream);
+/* dx = (gres ? gres : 0) + LN'(dy).  part: fp32 [vg_layernorm_bwd_parts(R)][3E] scratch holding per
+ * workgroup column sums (d gamma | d beta | colsum(dx)); fold with vg_colsum_f32. */
+int vg_layernorm_bwd_parts(int R);
+int vg_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                     const float* gamma, const void* gres, void* dx, float* part, int R, int E,
+                     void* stream);
+/* Self-modulated LayerNorm (src/v1/spectral_layer_norm.py:19-20): y = w*(gs*(LN(h)*lw+lb)+bs).
+ * h_bcast_rows > 0: h has that many rows and is broadcast over the batch (generator.py:62). */
+int vg_sln_fwd(const void* h, int h_bcast_rows, const void* w, const float* lw, const float* lb,
+               const float* gs, const float* bs, void* y, float* mean, float* rstd, int R, int E,
+               float eps, void* stream);
+/* part: fp32 [parts][3E+64]: d lw | d lb | colsum(dh) | d gs, d bs.  dw_acc fp32 [R,E]. */
+int vg_sln_bwd(const void* dy, const void* h, int h_bcast_rows, const void* w, const float* mean,
+               const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
+               const void* gres, void* dh, float* dw_acc, int dw_accumulate, float* part, int R,
+               int E, void* stream);
+/* dst_k[c] (+)= sum_r part[r][off_k + c] for up to 4 consecutive column segments (NULL = skip). */
+int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1,
+                  float* d2, int n2, float* d3, int n3, int accumulate, void* stream);
+
+/* Fused multi-head self-attention (src/v2/modules.py:128-159 after the projections; src/v1/attention.py
+ * :43-52,:97-101).  qkv bf16 [B*S, 3*H*HE] (Q | K | V thirds, head-major inside each third);
+ * out bf16 [B*S, H*HE]; lse fp32 [B,H,S].  softmax(scale * q.k).  HE in {32,64,96}, S <= 80. */
+int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE,
+                     float scale, void* stream);
+int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
+                     void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
+
+/* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1).
+ * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */
+int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role,
+                float grad_scale, void* stream);
+
+/* torch.optim.AdamW step over a flat fp32 buffer (src/v2/training.py:150-157), also refreshing the
+ * bf16 shadow the GEMMs read.  n % 4 == 0.  grads are multiplied by gscale first. */
+int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float gscale, void* stream);
+int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-network passes (what the nn.Modules call: one C call per forward / backward)
+ * ---------------------------------------------------------------------------------------- */
+
+/* v2 VisionTransformer (src/v2/modules.py:202-238) = ViTDiscriminator.forward (:393-395). */
+typedef struct VgVitDims {
+  int C, IH, P, E, H, L, R, Kc; /* channels, image size, patch, embed, heads, layers, mlp ratio, classes */
+} VgVitDims;
+/* Flat parameter layout (element offsets, identical for fp32 master, bf16 shadow, fp32 grads). */
+typedef struct VgVitLayout {
+  long long conv_w, conv_b, pos, cls;           /* embedding.conv1.weight [E,C*P*P], .bias, pos_embedding, cls_token */
+  long long layer0, layer_stride;               /* first encoder block, distance between blocks */
+  long long wqkv, wo, w1, w2;                   /* per block, relative: queries|keys|values [3E,E], out_projection, fc1, fc2 */
+  long long ln1_w, ln1_b, bqkv, bo, ln2_w, ln2_b, b1, b2;
+  long long layer_weights;                      /* elements in [wqkv, w2 end) */
+  long long lnf_w, lnf_b, hw1, hb1, hw2, hb2;   /* vit.norm, classifier.fc1, classifier.fc2 */
+  long long total;
+} VgVitLayout;
+int vg_vit_layout(const VgVitDims* d, VgVitLayout* out); /* host only */
+long long vg_vit_ws_bytes(const VgVitDims* d, int B);   /* host only: activation + scratch workspace */
+
+typedef struct VgVitNet {
+  VgVitDims d;
+  const float* P;   /* fp32 master parameters */
+  const void* Pb;   /* bf16 shadow of P */
+  float* G;         /* fp32 gradient accumulator (same layout); may be NULL when want_wgrad == 0 */
+} VgVitNet;
+/* img: [B,C,IH,IH] fp32 (img_is_bf16 = 0) or bf16; logits fp32 [B,Kc].  ws keeps everything the
+ * backward needs; one ws per in-flight forward. */
+int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws,
+                   float* logits, void* stream);
+/* dlogits fp32 [B,Kc].  d_img bf16 [B,C,IH,IH] or NULL.  want_wgrad: accumulate into net->G
+ * (G += dL/dP); 0 skips every weight-gradient kernel (generator pass through D, training.py:204-210). */
+int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img,
+                    int want_wgrad, void* stream);
+
+/* v1 generator: mapping Linear -> L x TransformerSLN -> SLN -> SIREN x2 (src/v1/generator.py:58-69). */
+typedef struct VgGenDims {
+  int Z, T, E, H, L, O, CW; /* latent, tokens, embed, heads, layers, siren hidden, channels*image_w */
+  float omega0;
+} VgGenDims;
+typedef struct VgGenLayout {
+  long long emb, map_w, map_b;                  /* embedding [T,E], mapping Linear [T*E, Z], bias */
+  long long layer0, layer_stride;
+  long long wqkv, wo, wm;                       /* per block, relative: all q heads | k heads | v heads [3E,E]; output_linear; mlp */
+  long long sln1_w, sln1_b, sln1_s, sln2_w, sln2_b, sln2_s, bo, bm; /* *_s: [gamma, beta] scalars */
+  long long layer_weights;
+  long long slnf_w, slnf_b, slnf_s, s1_w, s1_b, s2_w, s2_b;
+  long long total;
+} VgGenLayout;
+int vg_gen_layout(const VgGenDims* d, VgGenLayout* out);
+long long vg_gen_ws_bytes(const VgGenDims* d, int B);
+typedef struct VgGenNet {
+  VgGenDims d;
+  const float* P;
+  const void* Pb;
+  float* G;
+} VgGenNet;
+/* z fp32 [B,Z]; img bf16 [B, T*CW] (== [B,C,IH,IW] flat view, generator.py:66-68). */
+int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream);
+int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITGAN_HIP_H */

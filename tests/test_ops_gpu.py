@@ -1,0 +1,249 @@
+"""Parity of every HIP operator (called through the C ABI) against an fp32 PyTorch reference.
+
+Inputs are rounded to bf16 first, so the fp32 reference sees exactly what the kernel sees; the
+remaining difference is accumulation order (fp32) plus ONE bf16 rounding of the stored output:
+tolerance 2^-7 * max|ref| for bf16 outputs, 2e-5 * max|ref| for fp32 outputs (pre-activations,
+weight gradients, LSE, statistics).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF_TOL = 2.0 ** -7
+F32_TOL = 3e-5
+
+
+def _u():
+    import gpu_util
+    return gpu_util
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 384, 384), (260, 1152, 384), (77, 96, 768), (256, 384, 48), (64, 768, 96),
+                                   (1040, 768, 384)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_linear_fwd(M, N, K, act):
+    u = _u()
+    g = torch.Generator().manual_seed(M * 7 + N + K + act)
+    A = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    R = u.rbf(torch.randn(M, N, generator=g))
+    scale = 30.0 if act == 2 else 0.0
+    if act == 2:
+        W = u.rbf(W / 30.0)
+    pre = A @ W.t() + b
+    ref = {0: pre, 1: F.gelu(pre), 2: torch.sin(30.0 * pre), 3: torch.tanh(pre)}[act] + R
+    dA, dW, db, dR = u.dev(A, u.BF), u.dev(W, u.BF), u.dev(b), u.dev(R, u.BF)
+    out = torch.empty(M, N, dtype=u.BF, device="cuda")
+    pre_b = torch.empty(M, N, dtype=u.BF, device="cuda")
+    pre_f = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    u.call("vg_linear_fwd", u.ptr(dA), u.ptr(dW), u.ptr(db), u.ptr(dR), u.ptr(out), u.ptr(pre_b), u.ptr(pre_f),
+           M, N, K, act, scale, u.stream())
+    u.sync()
+    u.assert_close(pre_f, pre, F32_TOL, "pre_f32")
+    u.assert_close(pre_b, pre, BF_TOL, "pre_bf16")
+    u.assert_close(out, ref, BF_TOL, "out")
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 384, 384), (260, 1152, 384), (192, 768, 96), (256, 48, 384), (100, 96, 768)])
+@pytest.mark.parametrize("mul", [0, 4, 5])
+def test_linear_dgrad(M, N, K, mul):
+    u = _u()
+    g = torch.Generator().manual_seed(M + N * 3 + K + mul)
+    dY = u.rbf(torch.randn(M, N, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(N))
+    Z = u.rbf(torch.randn(M, K, generator=g))
+    Zf = torch.randn(M, K, generator=g) * 0.1
+    ref = dY @ W
+    if mul == 4:
+        zz = Z.clone().requires_grad_(True)
+        F.gelu(zz).sum().backward()
+        ref = ref * zz.grad
+    elif mul == 5:
+        ref = ref * 30.0 * torch.cos(30.0 * Zf)
+    out = torch.empty(M, K, dtype=u.BF, device="cuda")
+    dZ, dZf, ddY, dW_ = u.dev(Z, u.BF), u.dev(Zf), u.dev(dY, u.BF), u.dev(W, u.BF)  # keep alive across the call
+    u.call("vg_linear_dgrad", u.ptr(ddY), u.ptr(dW_), u.ptr(out), M, N, K, mul, u.ptr(dZ), u.ptr(dZf),
+           30.0, u.stream())
+    u.sync()
+    u.assert_close(out, ref, BF_TOL, "dX")
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(1040, 384, 384, 4), (650, 1152, 384, 3), (512, 96, 768, 2), (2048, 384, 48, 8),
+                                          (256, 384, 384, 1), (130, 768, 384, 5)])
+def test_linear_wgrad(M, N, K, splits):
+    u = _u()
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = u.rbf(torch.randn(M, N, generator=g))
+    X = u.rbf(torch.randn(M, K, generator=g))
+    prev = torch.randn(N, K, generator=g)
+    ref = dY.t() @ X
+    dW = u.dev(prev.clone())
+    slab = torch.empty(splits * N * K, dtype=torch.float32, device="cuda")
+    a, b = u.dev(dY, u.BF), u.dev(X, u.BF)
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 1, u.stream())
+    u.sync()
+    u.assert_close(dW, ref + prev, F32_TOL, "dW accumulate")
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 0, u.stream())
+    u.sync()
+    first = dW.clone()
+    u.assert_close(dW, ref, F32_TOL, "dW overwrite")
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 0, u.stream())
+    u.sync()
+    assert torch.equal(first, dW), "wgrad must be bitwise reproducible (no float atomics)"
+
+
+@pytest.mark.parametrize("R,E", [(130, 384), (65, 128), (33, 512), (7, 768)])
+def test_layernorm(R, E):
+    u = _u()
+    g = torch.Generator().manual_seed(R + E)
+    x = u.rbf(torch.randn(R, E, generator=g) * 2 + 0.5).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(E, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(E, generator=g)).requires_grad_(True)
+    dy = u.rbf(torch.randn(R, E, generator=g))
+    gres = u.rbf(torch.randn(R, E, generator=g))
+    y = F.layer_norm(x, (E,), gam, bet, 1e-5)
+    y.backward(dy)
+    dx_ref = x.grad + gres
+    X, Y = u.dev(x.detach(), u.BF), torch.empty(R, E, dtype=u.BF, device="cuda")
+    mean, rstd = torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    G_, B_ = u.dev(gam.detach()), u.dev(bet.detach())
+    u.call("vg_layernorm_fwd", u.ptr(X), E, u.ptr(G_), u.ptr(B_), u.ptr(Y), E, u.ptr(mean), u.ptr(rstd), R, E, 1e-5, u.stream())
+    u.sync()
+    u.assert_close(Y, y, BF_TOL, "ln y")
+    u.assert_close(mean, x.detach().mean(-1), F32_TOL, "mean")
+    parts = u._lib.lib().vg_layernorm_bwd_parts(R)
+    part = torch.zeros(parts, 3 * E, device="cuda")
+    dX = torch.empty(R, E, dtype=u.BF, device="cuda")
+    DY, GRES = u.dev(dy, u.BF), u.dev(gres, u.BF)
+    u.call("vg_layernorm_bwd", u.ptr(DY), u.ptr(X), u.ptr(mean), u.ptr(rstd), u.ptr(G_), u.ptr(GRES),
+           u.ptr(dX), u.ptr(part), R, E, u.stream())
+    dg, db, cs = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    u.call("vg_colsum_f32", u.ptr(part), parts, 3 * E, u.ptr(dg), E, u.ptr(db), E, u.ptr(cs), E, None, 0, 1, u.stream())
+    u.sync()
+    u.assert_close(dX, dx_ref, BF_TOL, "ln dx")
+    u.assert_close(dg, gam.grad, 2e-4, "dgamma")
+    u.assert_close(db, bet.grad, 2e-4, "dbeta")
+    u.assert_close(cs, dX.float().sum(0), 2e-4, "colsum(dx)")
+
+
+@pytest.mark.parametrize("B,T,E,bcast", [(3, 32, 384, True), (3, 32, 384, False), (2, 17, 128, False)])
+def test_sln(B, T, E, bcast):
+    u = _u()
+    g = torch.Generator().manual_seed(B + T + E + int(bcast))
+    R = B * T
+    h = u.rbf(torch.randn(T if bcast else R, E, generator=g)).requires_grad_(True)
+    w = u.rbf(torch.randn(R, E, generator=g)).requires_grad_(True)
+    lw = (1 + 0.1 * torch.randn(E, generator=g)).requires_grad_(True)
+    lb = (0.1 * torch.randn(E, generator=g)).requires_grad_(True)
+    sc = torch.tensor([0.7, -0.4]).requires_grad_(True)  # gamma, beta
+    dy = u.rbf(torch.randn(R, E, generator=g))
+    gres = u.rbf(torch.randn(R, E, generator=g))
+    hh = h.repeat(B, 1) if bcast else h
+    y = sc[0] * w * F.layer_norm(hh, (E,), lw, lb, 1e-5) + sc[1] * w
+    y.backward(dy)
+    H, W = u.dev(h.detach(), u.BF), u.dev(w.detach(), u.BF)
+    LW, LB, SC = u.dev(lw.detach()), u.dev(lb.detach()), u.dev(sc.detach())
+    Y = torch.empty(R, E, dtype=u.BF, device="cuda")
+    mean, rstd = torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    import ctypes as C
+    gs, bs = u.ptr(SC), C.c_void_p(SC.data_ptr() + 4)
+    hb = T if bcast else 0
+    u.call("vg_sln_fwd", u.ptr(H), hb, u.ptr(W), u.ptr(LW), u.ptr(LB), gs, bs, u.ptr(Y), u.ptr(mean), u.ptr(rstd), R, E, 1e-5, u.stream())
+    u.sync()
+    u.assert_close(Y, y, BF_TOL, "sln y")
+    parts = u._lib.lib().vg_layernorm_bwd_parts(R)
+    PW = 3 * E + 64
+    part = torch.zeros(parts, PW, device="cuda")
+    dH = torch.empty(R, E, dtype=u.BF, device="cuda")
+    dwacc = torch.ones(R, E, device="cuda")
+    DY, GRES = u.dev(dy, u.BF), u.dev(gres, u.BF)
+    u.call("vg_sln_bwd", u.ptr(DY), u.ptr(H), hb, u.ptr(W), u.ptr(mean), u.ptr(rstd), u.ptr(LW), u.ptr(LB), gs, bs,
+           u.ptr(GRES), u.ptr(dH), u.ptr(dwacc), 1, u.ptr(part), R, E, u.stream())
+    dlw, dlb, cs = (torch.zeros(E, device="cuda") for _ in range(3))
+    dsc = torch.zeros(2, device="cuda")
+    u.call("vg_colsum_f32", u.ptr(part), parts, PW, u.ptr(dlw), E, u.ptr(dlb), E, u.ptr(cs), E, u.ptr(dsc), 2, 1, u.stream())
+    u.sync()
+    dh_full = (h.grad if not bcast else None)
+    if bcast:  # per-row dh before the batch sum: recompute with an expanded leaf
+        h2 = h.detach().repeat(B, 1).requires_grad_(True)
+        (sc[0].detach() * w.detach() * F.layer_norm(h2, (E,), lw.detach(), lb.detach(), 1e-5)).backward(dy)
+        dh_full = h2.grad
+    u.assert_close(dH, dh_full + gres, BF_TOL, "sln dh")
+    u.assert_close(dwacc, w.grad + 1.0, 1e-4, "sln dw (accumulate)")
+    u.assert_close(dlw, lw.grad, 3e-4, "dlw")
+    u.assert_close(dlb, lb.grad, 3e-4, "dlb")
+    u.assert_close(dsc, sc.grad, 3e-4, "dgamma/dbeta")
+
+
+@pytest.mark.parametrize("B,H,S,HE,scale", [(3, 4, 65, 96, None), (2, 4, 32, 96, 1 / math.sqrt(384)), (2, 8, 65, 64, None),
+                                            (2, 4, 65, 32, None), (2, 2, 17, 64, None), (1, 4, 80, 96, None), (2, 4, 1, 32, None)])
+def test_attention(B, H, S, HE, scale):
+    u = _u()
+    E = H * HE
+    scale = scale or 1 / math.sqrt(HE)
+    g = torch.Generator().manual_seed(B + H + S + HE)
+    qkv = u.rbf(torch.randn(B * S, 3 * E, generator=g) * 1.5).requires_grad_(True)
+    dO = u.rbf(torch.randn(B * S, E, generator=g))
+    q, k, v = (qkv[:, i * E:(i + 1) * E].reshape(B, S, H, HE).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) * scale
+    p = torch.softmax(sc, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * S, E)
+    lse_ref = torch.logsumexp(sc, -1)
+    QKV = u.dev(qkv.detach(), u.BF)
+    O = torch.empty(B * S, E, dtype=u.BF, device="cuda")
+    LSE = torch.empty(B, H, S, device="cuda")
+    u.call("vg_attention_fwd", u.ptr(QKV), u.ptr(O), u.ptr(LSE), B, H, S, HE, scale, u.stream())
+    u.sync()
+    u.assert_close(LSE, lse_ref, 1e-4, "lse")
+    u.assert_close(O, o, 2.0 ** -6, "attn out")  # P is rounded to bf16 before P.V: one extra bf16 rounding
+    o.backward(dO)
+    dQKV = torch.empty(B * S, 3 * E, dtype=u.BF, device="cuda")
+    DO = u.dev(dO, u.BF)
+    u.call("vg_attention_bwd", u.ptr(QKV), u.ptr(O), u.ptr(DO), u.ptr(LSE), u.ptr(dQKV), B, H, S, HE, scale, u.stream())
+    u.sync()
+    for i, nm in enumerate("qkv"):
+        u.assert_close(dQKV[:, i * E:(i + 1) * E], qkv.grad[:, i * E:(i + 1) * E], 2.0 ** -5, f"d{nm}")
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("role", [0, 1, 2])
+def test_gan_loss(kind, role):
+    u = _u()
+    from oracle import step_oracle as so
+    x = (torch.randn(300, generator=torch.Generator().manual_seed(role + 3 * kind)) * 2).requires_grad_(True)
+    name = "ns" if kind == 0 else "hinge"
+    loss = [so.d_loss_real, so.d_loss_fake, so.g_loss][role](x, name)
+    loss.backward()
+    X = u.dev(x.detach())
+    d = torch.empty(300, device="cuda")
+    lo = torch.zeros(1, device="cuda")
+    u.call("vg_gan_loss", u.ptr(X), u.ptr(d), u.ptr(lo), 300, kind, role, 1.0, u.stream())
+    u.sync()
+    u.assert_close(lo, loss.detach().reshape(1), 1e-5, "loss")
+    u.assert_close(d, x.grad, 1e-5, "dlogits")
+
+
+def test_adamw_matches_torch():
+    u = _u()
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=5e-4, weight_decay=1e-3)
+    P, M_, V_ = u.dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    SH = torch.empty(n, dtype=u.BF, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        GR = u.dev(gr * 2.0)
+        u.call("vg_adamw_step", u.ptr(P), u.ptr(GR), u.ptr(M_), u.ptr(V_), u.ptr(SH), n, 5e-4, 0.9, 0.999, 1e-8, 1e-3,
+               step, 0.5, u.stream())
+        u.sync()
+        u.assert_close(P, p.detach(), 1e-6, f"adamw step {step}")
+        u.assert_close(SH, p.detach(), 2.0 ** -8, "bf16 shadow")

@@ -1,0 +1,115 @@
+"""ctypes binding of libvitgan_hip.so (C ABI: include/vitgan_hip.h).
+
+There is no CPU fallback: if the library is missing every operator raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitgan_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class VgVitDims(C.Structure):
+    _fields_ = [(n, c_int) for n in ("C", "IH", "P", "E", "H", "L", "R", "Kc")]
+
+
+class VgVitLayout(C.Structure):
+    _fields_ = [(n, c_ll) for n in (
+        "conv_w", "conv_b", "pos", "cls", "layer0", "layer_stride", "wqkv", "wo", "w1", "w2",
+        "ln1_w", "ln1_b", "bqkv", "bo", "ln2_w", "ln2_b", "b1", "b2", "layer_weights",
+        "lnf_w", "lnf_b", "hw1", "hb1", "hw2", "hb2", "total")]
+
+
+class VgVitNet(C.Structure):
+    _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p)]
+
+
+class VgGenDims(C.Structure):
+    _fields_ = [(n, c_int) for n in ("Z", "T", "E", "H", "L", "O", "CW")] + [("omega0", c_float)]
+
+
+class VgGenLayout(C.Structure):
+    _fields_ = [(n, c_ll) for n in (
+        "emb", "map_w", "map_b", "layer0", "layer_stride", "wqkv", "wo", "wm",
+        "sln1_w", "sln1_b", "sln1_s", "sln2_w", "sln2_b", "sln2_s", "bo", "bm", "layer_weights",
+        "slnf_w", "slnf_b", "slnf_s", "s1_w", "s1_b", "s2_w", "s2_b", "total")]
+
+
+class VgGenNet(C.Structure):
+    _fields_ = [("d", VgGenDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    "vg_abi_version": (c_int, []),
+    "vg_linear_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_linear_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_float, P]),
+    "vg_linear_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vg_layernorm_fwd": (c_int, [P, c_ll, P, P, P, c_ll, P, P, c_int, c_int, c_float, P]),
+    "vg_layernorm_bwd_parts": (c_int, [c_int]),
+    "vg_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "vg_sln_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_float, P]),
+    "vg_sln_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, P]),
+    "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
+    "vg_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
+    "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "vg_cast_f32_bf16": (c_int, [P, P, c_ll, P]),
+    "vg_vit_layout": (c_int, [C.POINTER(VgVitDims), C.POINTER(VgVitLayout)]),
+    "vg_vit_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
+    "vg_vit_forward": (c_int, [C.POINTER(VgVitNet), c_int, P, c_int, P, P, P]),
+    "vg_vit_backward": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, P]),
+    "vg_gen_layout": (c_int, [C.POINTER(VgGenDims), C.POINTER(VgGenLayout)]),
+    "vg_gen_ws_bytes": (c_ll, [C.POINTER(VgGenDims), c_int]),
+    "vg_gen_forward": (c_int, [C.POINTER(VgGenNet), c_int, P, P, P, P]),
+    "vg_gen_backward": (c_int, [C.POINTER(VgGenNet), c_int, P, P, P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libvitgan_hip.so (hipcc cross-compiles without a GPU)."""
+    jobs = str(min(6, os.cpu_count() or 1))
+    r = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("libvitgan_hip.so build failed")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only compute path of this package. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.vg_abi_version() != 1:
+            raise RuntimeError("libvitgan_hip.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "argument validation" if rc < 0 else "hipError_t"
+        raise HipError(f"{what} failed: {kind} {rc}")

@@ -1,0 +1,91 @@
+// extern "C" single-operator entry points of include/vitgan_hip.h (thin argument adapters).
+#include "../../include/vitgan_hip.h"
+#include "vg_kernels.h"
+
+extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
+
+extern "C" int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* res, void* C, void* pre_bf16,
+                             float* pre_f32, int M, int N, int K, int act, float act_scale, void* stream) {
+  if (!A || !W || (!C && !pre_bf16 && !pre_f32)) return -1;
+  if (act < 0 || act > 3) return -4;
+  VgGemmProb p = vg_gemm_prob();
+  p.A = (const bf16*)A; p.lda = K; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = N; p.K = K;
+  p.C = (bf16*)C; p.ldc = N; p.bias = bias; p.res = (const bf16*)res; p.ldr = N; p.C2 = (bf16*)pre_bf16; p.ldc2 = N;
+  if (pre_f32) { p.pre_f32 = 1; p.Cf = pre_f32; p.ldcf = N; }
+  p.act = act; p.act_scale = act_scale;
+  return vg_gemm_launch(&p, 1, VG_NT, (hipStream_t)stream);
+}
+extern "C" int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode, const void* Z,
+                               const float* Zf, float act_scale, void* stream) {
+  if (!dY || !W || !dX) return -1;
+  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS) return -4;
+  if ((mul_mode == VG_ACT_MUL_GELU_GRAD && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
+  VgGemmProb p = vg_gemm_prob();
+  p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = K; p.K = N;
+  p.C = (bf16*)dX; p.ldc = K; p.act = mul_mode; p.act_scale = act_scale;
+  p.Z = (const bf16*)Z; p.ldz = K; p.Zf = Zf; p.ldzf = K;
+  return vg_gemm_launch(&p, 1, VG_NN, (hipStream_t)stream);
+}
+extern "C" int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, int M, int N, int K, int splits,
+                               int accumulate, void* stream) {
+  if (!dY || !X || !dW || !slab_ws || splits < 1) return -1;
+  VgGemmProb p = vg_gemm_prob();
+  p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)X; p.ldb = K; p.M = N; p.N = K; p.K = M;
+  p.Cf = slab_ws; p.ldcf = K; p.cf_split_stride = (long long)N * K; p.splits = splits;
+  VG_TRY(vg_gemm_launch(&p, 1, VG_TN, (hipStream_t)stream));
+  return vg_slab_reduce_launch(slab_ws, (long long)N * K, p.splits, dW, (long long)N * K, accumulate, (hipStream_t)stream);
+}
+extern "C" int vg_layernorm_fwd(const void* x, long long xs, const float* gamma, const float* beta, void* y, long long ys,
+                                float* mean, float* rstd, int R, int E, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return -1;
+  return vg_ln_fwd_launch((const bf16*)x, xs, gamma, beta, (bf16*)y, ys, mean, rstd, R, E, eps, (hipStream_t)stream);
+}
+extern "C" int vg_layernorm_bwd_parts(int R) { return vg_ln_bwd_nparts(R); }
+extern "C" int vg_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const void* gres, void* dx, float* part, int R, int E, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !part) return -1;
+  return vg_ln_bwd_launch((const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)gres, (bf16*)dx, part, R, E,
+                          (hipStream_t)stream);
+}
+extern "C" int vg_sln_fwd(const void* h, int h_bcast_rows, const void* w, const float* lw, const float* lb, const float* gs,
+                          const float* bs, void* y, float* mean, float* rstd, int R, int E, float eps, void* stream) {
+  if (!h || !w || !lw || !lb || !gs || !bs || !y || !mean || !rstd) return -1;
+  return vg_sln_fwd_launch((const bf16*)h, h_bcast_rows, (const bf16*)w, lw, lb, gs, bs, (bf16*)y, mean, rstd, R, E, eps,
+                           (hipStream_t)stream);
+}
+extern "C" int vg_sln_bwd(const void* dy, const void* h, int h_bcast_rows, const void* w, const float* mean, const float* rstd,
+                          const float* lw, const float* lb, const float* gs, const float* bs, const void* gres, void* dh,
+                          float* dw_acc, int dw_accumulate, float* part, int R, int E, void* stream) {
+  if (!dy || !h || !w || !mean || !rstd || !lw || !lb || !gs || !bs || !dh || !dw_acc || !part) return -1;
+  return vg_sln_bwd_launch((const bf16*)dy, (const bf16*)h, h_bcast_rows, (const bf16*)w, mean, rstd, lw, lb, gs, bs,
+                           (const bf16*)gres, (bf16*)dh, dw_acc, dw_accumulate, part, R, E, (hipStream_t)stream);
+}
+extern "C" int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
+                             float* d3, int n3, int accumulate, void* stream) {
+  if (!part || rows < 1 || width < 1) return -1;
+  return vg_colsum_f32_launch(part, rows, width, d0, n0, d1, n1, d2, n2, d3, n3, accumulate, (hipStream_t)stream);
+}
+extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !lse) return -1;
+  return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, (hipStream_t)stream);
+}
+extern "C" int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* d_qkv, int B, int H,
+                                int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !d_out || !lse || !d_qkv) return -1;
+  return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale,
+                            (hipStream_t)stream);
+}
+extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role, float grad_scale,
+                           void* stream) {
+  if (!logits || !dlogits || !loss_out || n < 1) return -1;
+  return vg_gan_loss_launch(logits, dlogits, loss_out, n, kind, role, grad_scale, (hipStream_t)stream);
+}
+extern "C" int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float gscale, void* stream) {
+  if (!p || !g || !m || !v || !shadow_bf16 || n < 1 || step < 1) return -1;
+  return vg_adamw_launch(p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, gscale, (hipStream_t)stream);
+}
+extern "C" int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
+  if (!src || !dst_bf16 || n < 1) return -1;
+  return vg_cast_f32_bf16_launch(src, (bf16*)dst_bf16, n, (hipStream_t)stream);
+}

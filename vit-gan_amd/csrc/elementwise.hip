@@ -1,0 +1,303 @@
+// Patchify / un-patchify, CLS/positional bookkeeping, classifier head, GAN losses, fused AdamW
+// and the casts around them.  All memory-bound, coalesced, deterministic (no float atomics).
+#include "vg_common.h"
+
+// ---- patchify: NCHW image -> [B*NP, C*P*P] bf16 rows in (c, py, px) order ----------------------
+// (the memory order of conv1.weight[e], src/v2/modules.py:70-72, so the conv is one NT GEMM)
+template <typename T>
+__global__ __launch_bounds__(256) void vg_patchify_kernel(const T* __restrict__ img, bf16* __restrict__ A, int B, int C,
+                                                          int IH, int P) {
+  const int G = IH / P, K = C * P * P;
+  const long long total = (long long)B * C * IH * G;  // one thread per (b, c, y, gx): P contiguous pixels
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int gx = (int)(i % G);
+  long long t = i / G;
+  const int y = (int)(t % IH); t /= IH;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  const int gy = y / P, py = y - gy * P;
+  const T* src = img + (((size_t)b * C + c) * IH + y) * IH + gx * P;
+  bf16* dst = A + ((size_t)b * G * G + gy * G + gx) * K + (c * P + py) * P;
+  for (int px = 0; px < P; ++px) dst[px] = vg_f2bf((float)src[px]);
+}
+// ---- inverse of the above for gradients: dA [B*NP, K] bf16 -> d_img [B,C,IH,IH] bf16 -----------
+__global__ __launch_bounds__(256) void vg_unpatchify_kernel(const bf16* __restrict__ dA, bf16* __restrict__ dimg, int B,
+                                                            int C, int IH, int P) {
+  const int G = IH / P, K = C * P * P;
+  const long long total = (long long)B * C * IH * G;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int gx = (int)(i % G);
+  long long t = i / G;
+  const int y = (int)(t % IH); t /= IH;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  const int gy = y / P, py = y - gy * P;
+  bf16* dst = dimg + (((size_t)b * C + c) * IH + y) * IH + gx * P;
+  const bf16* src = dA + ((size_t)b * G * G + gy * G + gx) * K + (c * P + py) * P;
+  for (int px = 0; px < P; ++px) dst[px] = src[px];
+}
+
+// ---- CLS rows of the token matrix: x[b*S + 0, :] = cls ------------------------------------------
+__global__ __launch_bounds__(256) void vg_fill_cls_kernel(bf16* __restrict__ x, const float* __restrict__ cls, int B, int S,
+                                                          int E) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, e = i - b * E;
+  x[(size_t)b * S * E + e] = vg_f2bf(cls[e]);
+}
+// ---- gather / scatter of row subsets ---------------------------------------------------------
+// out[(b*n_take + j), :] = in[(b*S + first + j), :]      (16 B per thread)
+__global__ __launch_bounds__(256) void vg_take_rows_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int B, int S,
+                                                           int first, int n_take, int E) {
+  const int cpr = E / 8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * n_take * cpr) return;
+  const int c = (int)(i % cpr);
+  const long long r = i / cpr;
+  const int b = (int)(r / n_take), j = (int)(r - (long long)b * n_take);
+  *(u32x4*)(out + (size_t)r * E + 8 * c) = *(const u32x4*)(in + ((size_t)b * S + first + j) * E + 8 * c);
+}
+// g[(b*S + 0), :] = src[b, :], every other row of g = 0
+__global__ __launch_bounds__(256) void vg_scatter_cls_kernel(const bf16* __restrict__ src, bf16* __restrict__ g, int B, int S,
+                                                             int E) {
+  const int cpr = E / 8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * S * cpr) return;
+  const int c = (int)(i % cpr);
+  const long long r = i / cpr;
+  const int b = (int)(r / S), s = (int)(r - (long long)b * S);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (s == 0) v = *(const u32x4*)(src + (size_t)b * E + 8 * c);
+  *(u32x4*)(g + (size_t)r * E + 8 * c) = v;
+}
+// out[s, e] = sum_b g[(b*S + s), e]   (fp32, one thread per (s, e) pair of columns)
+__global__ __launch_bounds__(256) void vg_batch_sum_kernel(const bf16* __restrict__ g, float* __restrict__ out, int B, int S,
+                                                           int E) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * (E / 2)) return;
+  const int s = i / (E / 2), e = 2 * (i - s * (E / 2));
+  float a0 = 0.f, a1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const bf16x2 t = *(const bf16x2*)(g + ((size_t)b * S + s) * E + e);
+    a0 += vg_bf2f(t[0]); a1 += vg_bf2f(t[1]);
+  }
+  out[(size_t)s * E + e] = a0; out[(size_t)s * E + e + 1] = a1;
+}
+// embed grads from tok_sum [S,E]: d_cls += tok_sum[0]; d_pos += tok_sum[1:]; d_convbias += sum_n tok_sum[1+n]
+__global__ __launch_bounds__(256) void vg_embed_small_grads_kernel(const float* __restrict__ tok_sum, float* __restrict__ d_cls,
+                                                                   float* __restrict__ d_pos, float* __restrict__ d_bias, int S,
+                                                                   int E) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  d_cls[e] += tok_sum[e];
+  float a = 0.f;
+  for (int n = 1; n < S; ++n) {
+    const float t = tok_sum[(size_t)n * E + e];
+    d_pos[(size_t)(n - 1) * E + e] += t;
+    a += t;
+  }
+  d_bias[e] += a;
+}
+
+// ---- classifier tail: logits[b,k] = t[b,:] . W2[k,:] + b2[k]   (one wave per (b,k)) -------------
+__global__ __launch_bounds__(256) void vg_head_fc2_kernel(const bf16* __restrict__ t, const float* __restrict__ W2,
+                                                          const float* __restrict__ b2, float* __restrict__ logits, int B, int E,
+                                                          int Kc) {
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= B * Kc) return;
+  const int b = wv / Kc, k = wv - b * Kc;
+  float a = 0.f;
+  for (int e = lane; e < E; e += 64) a += vg_bf2f(t[(size_t)b * E + e]) * W2[(size_t)k * E + e];
+  a = vg_wave_sum(a);
+  if (lane == 0) logits[wv] = a + b2[k];
+}
+// dz1[b,e] = (sum_k dlog[b,k] W2[k,e]) * (1 - t[b,e]^2)
+__global__ __launch_bounds__(256) void vg_head_bwd_dz_kernel(const float* __restrict__ dlog, const float* __restrict__ W2,
+                                                             const bf16* __restrict__ t, bf16* __restrict__ dz, int B, int E,
+                                                             int Kc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, e = i - b * E;
+  float a = 0.f;
+  for (int k = 0; k < Kc; ++k) a += dlog[b * Kc + k] * W2[(size_t)k * E + e];
+  const float tv = vg_bf2f(t[i]);
+  dz[i] = vg_f2bf(a * (1.f - tv * tv));
+}
+// dW2[k,e] += sum_b dlog[b,k] t[b,e];  db2[k] += sum_b dlog[b,k]
+__global__ __launch_bounds__(256) void vg_head_bwd_w2_kernel(const float* __restrict__ dlog, const bf16* __restrict__ t,
+                                                             float* __restrict__ dW2, float* __restrict__ db2, int B, int E,
+                                                             int Kc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Kc * (E + 1)) return;
+  const int k = i / (E + 1), e = i - k * (E + 1);
+  float a = 0.f;
+  if (e < E) {
+    for (int b = 0; b < B; ++b) a += dlog[b * Kc + k] * vg_bf2f(t[(size_t)b * E + e]);
+    dW2[(size_t)k * E + e] += a;
+  } else {
+    for (int b = 0; b < B; ++b) a += dlog[b * Kc + k];
+    db2[k] += a;
+  }
+}
+
+// ---- GAN losses on logits [n] ------------------------------------------------------------------
+// kind: 0 = non-saturating BCE-with-logits (v1 gan.py:16-20 semantics), 1 = hinge.
+// role: 0 = D on real (target 1), 1 = D on fake (target 0), 2 = G (target 1 / -mean).
+// loss_out[0] = mean loss; dlog[i] = d(mean loss)/d logit[i] * grad_scale.
+__global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restrict__ logit, float* __restrict__ dlog,
+                                                          float* __restrict__ loss_out, int n, int kind, int role,
+                                                          float grad_scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 1.0f / (float)n;
+  // branch-free on purpose: both losses are evaluated and selected (uniform kind/role)
+  const float t = (role == 1) ? 0.f : 1.f;      // BCE target
+  const float sgn = (role == 1) ? 1.f : -1.f;   // hinge: relu(1 + sgn*x)
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float x = logit[i];
+    const float l_ns = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+    const float d_ns = 1.f / (1.f + __expf(-x)) - t;
+    const float hm = 1.f + sgn * x;
+    const float l_h = (role == 2) ? -x : fmaxf(hm, 0.f);
+    const float d_h = (role == 2) ? -1.f : ((hm > 0.f) ? sgn : 0.f);
+    const float l = (kind == 0) ? l_ns : l_h;
+    const float d = (kind == 0) ? d_ns : d_h;
+    acc += l;
+    dlog[i] = d * inv * grad_scale;
+  }
+  acc = vg_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+}
+
+// ---- fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics) ----------------------
+// p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps);  shadow = bf16(p).   g is pre-scaled by gscale.
+__global__ __launch_bounds__(256) void vg_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, bf16* __restrict__ shadow, long long n, float lr,
+                                                       float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                       float gscale) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  f32x4 pv = *(f32x4*)(p + i4), gv = *(const f32x4*)(g + i4), mv = *(f32x4*)(m + i4), vv = *(f32x4*)(v + i4);
+  bf16x4 sh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gg = gv[j] * gscale;
+    float pp = pv[j] * (1.f - lr * wd);
+    const float mm = b1 * mv[j] + (1.f - b1) * gg;
+    const float v2 = b2 * vv[j] + (1.f - b2) * gg * gg;
+    pp -= (lr / bc1) * mm / (sqrtf(v2) / bc2_sqrt + eps);
+    pv[j] = pp; mv[j] = mm; vv[j] = v2; sh[j] = vg_f2bf(pp);
+  }
+  *(f32x4*)(p + i4) = pv; *(f32x4*)(m + i4) = mv; *(f32x4*)(v + i4) = vv;
+  *(bf16x4*)(shadow + i4) = sh;
+}
+__global__ __launch_bounds__(256) void vg_cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long n) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const f32x4 s = *(const f32x4*)(src + i4);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = vg_f2bf(s[j]);
+  *(bf16x4*)(dst + i4) = o;
+}
+// dst[i] (+)= sum_s slab[s][i]   (wgrad split-K slabs -> gradient buffer)
+__global__ __launch_bounds__(256) void vg_slab_reduce_kernel(const float* __restrict__ slab, long long stride, int nslab,
+                                                             float* __restrict__ dst, long long n, int accumulate) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  f32x4 a = accumulate ? *(const f32x4*)(dst + i4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslab; ++s) a += *(const f32x4*)(slab + (size_t)s * stride + i4);
+  *(f32x4*)(dst + i4) = a;
+}
+// SIREN output-layer gradient: dz = dy * w0 * cos(w0 * z)   (z fp32 pre-activation)
+__global__ __launch_bounds__(256) void vg_sin_grad_kernel(const bf16* __restrict__ dy, const float* __restrict__ z,
+                                                          bf16* __restrict__ dz, long long n, float w0) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const bf16x4 d = *(const bf16x4*)(dy + i4);
+  const f32x4 zz = *(const f32x4*)(z + i4);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = vg_f2bf(vg_bf2f(d[j]) * w0 * __cosf(w0 * zz[j]));
+  *(bf16x4*)(dz + i4) = o;
+}
+
+// --------------------------------------- launchers ---------------------------------------------
+static inline unsigned nblk(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+int vg_patchify_launch(const void* img, int img_is_bf16, bf16* A, int B, int C, int IH, int P, hipStream_t st) {
+  if (IH % P) return -3;
+  const long long total = (long long)B * C * IH * (IH / P);
+  if (img_is_bf16) hipLaunchKernelGGL(vg_patchify_kernel<bf16>, dim3(nblk(total)), dim3(256), 0, st, (const bf16*)img, A, B, C, IH, P);
+  else hipLaunchKernelGGL(vg_patchify_kernel<float>, dim3(nblk(total)), dim3(256), 0, st, (const float*)img, A, B, C, IH, P);
+  return (int)hipGetLastError();
+}
+int vg_unpatchify_launch(const bf16* dA, bf16* dimg, int B, int C, int IH, int P, hipStream_t st) {
+  const long long total = (long long)B * C * IH * (IH / P);
+  hipLaunchKernelGGL(vg_unpatchify_kernel, dim3(nblk(total)), dim3(256), 0, st, dA, dimg, B, C, IH, P);
+  return (int)hipGetLastError();
+}
+int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, hipStream_t st) {
+  hipLaunchKernelGGL(vg_fill_cls_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, x, cls, B, S, E);
+  return (int)hipGetLastError();
+}
+int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int n_take, int E, hipStream_t st) {
+  hipLaunchKernelGGL(vg_take_rows_kernel, dim3(nblk((long long)B * n_take * (E / 8))), dim3(256), 0, st, in, out, B, S, first, n_take, E);
+  return (int)hipGetLastError();
+}
+int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st) {
+  hipLaunchKernelGGL(vg_scatter_cls_kernel, dim3(nblk((long long)B * S * (E / 8))), dim3(256), 0, st, src, g, B, S, E);
+  return (int)hipGetLastError();
+}
+int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st) {
+  hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(nblk((long long)S * (E / 2))), dim3(256), 0, st, g, out, B, S, E);
+  return (int)hipGetLastError();
+}
+int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st) {
+  hipLaunchKernelGGL(vg_embed_small_grads_kernel, dim3(nblk(E)), dim3(256), 0, st, tok_sum, d_cls, d_pos, d_bias, S, E);
+  return (int)hipGetLastError();
+}
+int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* logits, int B, int E, int Kc, hipStream_t st) {
+  hipLaunchKernelGGL(vg_head_fc2_kernel, dim3(nblk((long long)B * Kc, 4)), dim3(256), 0, st, t, W2, b2, logits, B, E, Kc);
+  return (int)hipGetLastError();
+}
+int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* dz, float* dW2, float* db2, int B, int E, int Kc,
+                       int want_wgrad, hipStream_t st) {
+  hipLaunchKernelGGL(vg_head_bwd_dz_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, dlog, W2, t, dz, B, E, Kc);
+  if (want_wgrad)
+    hipLaunchKernelGGL(vg_head_bwd_w2_kernel, dim3(nblk((long long)Kc * (E + 1))), dim3(256), 0, st, dlog, t, dW2, db2, B, E, Kc);
+  return (int)hipGetLastError();
+}
+int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
+                       hipStream_t st) {
+  if (kind < 0 || kind > 1 || role < 0 || role > 2) return -2;
+  hipLaunchKernelGGL(vg_gan_loss_kernel, dim3(1), dim3(256), 0, st, logit, dlog, loss_out, n, kind, role, grad_scale);
+  return (int)hipGetLastError();
+}
+int vg_adamw_launch(float* p, const float* g, float* m, float* v, bf16* shadow, long long n, float lr, float b1, float b2,
+                    float eps, float wd, int step, float gscale, hipStream_t st) {
+  if (n & 3) return -3;
+  const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
+  hipLaunchKernelGGL(vg_adamw_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, p, g, m, v, shadow, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+  return (int)hipGetLastError();
+}
+int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_t st) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(vg_cast_f32_bf16_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, src, dst, n);
+  return (int)hipGetLastError();
+}
+int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(vg_slab_reduce_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, slab, stride, nslab, dst, n, accumulate);
+  return (int)hipGetLastError();
+}
+int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(vg_sin_grad_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, dy, z, dz, n, w0);
+  return (int)hipGetLastError();
+}

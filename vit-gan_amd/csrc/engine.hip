@@ -1,0 +1,530 @@
+// Whole-network passes: sequences the gfx950 kernels for the v2 VisionTransformer (discriminator)
+// and the v1 SLN/SIREN generator.  Host code only enqueues work on one stream: no allocation, no
+// synchronisation, so a pass (or a whole G/D step) can be captured into a hipGraph by the caller.
+//
+// Data layout (all row-major, bf16 unless noted):
+//   tokens      X[l]   [B*S, E]      residual stream entering block l (X[L] = trunk output)
+//   qkv[l]             [B*S, 3E]     Q | K | V thirds, head h at columns h*HE.. of each third
+//   flat params        fp32 master P, bf16 shadow Pb, fp32 grads G share ONE offset table
+//                      (VgVitLayout / VgGenLayout): per block the four GEMM weights are contiguous so
+//                      their split-K wgrad slabs fold into G with a single streaming kernel.
+#include "../../include/vitgan_hip.h"
+#include "vg_kernels.h"
+
+static inline long long al64(long long x) { return (x + 63) & ~63LL; }
+
+// =============================================================================================
+//                                       layouts
+// =============================================================================================
+extern "C" int vg_vit_layout(const VgVitDims* d, VgVitLayout* o) {
+  if (!d || !o) return -1;
+  const long long E = d->E, K = (long long)d->C * d->P * d->P, NP = (long long)(d->IH / d->P) * (d->IH / d->P);
+  if (d->E % 128 || d->E % d->H || d->IH % d->P || (K & 7) || d->L < 1 || d->Kc < 1 || d->R < 1) return -3;
+  const int HE = d->E / d->H;
+  if (HE != 32 && HE != 64 && HE != 96) return -3;
+  if (NP + 1 > 80) return -3;
+  long long p = 0;
+  o->conv_w = p; p = al64(p + E * K);
+  o->conv_b = p; p = al64(p + E);
+  o->pos = p; p = al64(p + NP * E);
+  o->cls = p; p = al64(p + E);
+  // per block (relative offsets)
+  long long q = 0;
+  o->wqkv = q; q += 3 * E * E;
+  o->wo = q; q += E * E;
+  o->w1 = q; q += (long long)d->R * E * E;
+  o->w2 = q; q += (long long)d->R * E * E;
+  o->layer_weights = q;
+  o->ln1_w = q; q = al64(q + E);
+  o->ln1_b = q; q = al64(q + E);
+  o->bqkv = q; q = al64(q + 3 * E);
+  o->bo = q; q = al64(q + E);
+  o->ln2_w = q; q = al64(q + E);
+  o->ln2_b = q; q = al64(q + E);
+  o->b1 = q; q = al64(q + (long long)d->R * E);
+  o->b2 = q; q = al64(q + E);
+  o->layer0 = p; o->layer_stride = q;
+  p += q * d->L;
+  o->lnf_w = p; p = al64(p + E);
+  o->lnf_b = p; p = al64(p + E);
+  o->hw1 = p; p = al64(p + E * E);
+  o->hb1 = p; p = al64(p + E);
+  o->hw2 = p; p = al64(p + (long long)d->Kc * E);
+  o->hb2 = p; p = al64(p + d->Kc);
+  o->total = p;
+  return 0;
+}
+
+extern "C" int vg_gen_layout(const VgGenDims* d, VgGenLayout* o) {
+  if (!d || !o) return -1;
+  const long long E = d->E, T = d->T;
+  if (d->E % 128 || d->E % d->H || (d->Z & 7) || (d->O & 7) || (d->CW & 7) || d->T > 80 || d->L < 1) return -3;
+  const int HE = d->E / d->H;
+  if (HE != 32 && HE != 64 && HE != 96) return -3;
+  long long p = 0;
+  o->emb = p; p = al64(p + T * E);
+  o->map_w = p; p = al64(p + T * E * d->Z);
+  o->map_b = p; p = al64(p + T * E);
+  long long q = 0;
+  o->wqkv = q; q += 3 * E * E;
+  o->wo = q; q += E * E;
+  o->wm = q; q += E * E;
+  o->layer_weights = q;
+  o->sln1_w = q; q = al64(q + E);
+  o->sln1_b = q; q = al64(q + E);
+  o->sln1_s = q; q = al64(q + 2);
+  o->sln2_w = q; q = al64(q + E);
+  o->sln2_b = q; q = al64(q + E);
+  o->sln2_s = q; q = al64(q + 2);
+  o->bo = q; q = al64(q + E);
+  o->bm = q; q = al64(q + E);
+  o->layer0 = p; o->layer_stride = q;
+  p += q * d->L;
+  o->slnf_w = p; p = al64(p + E);
+  o->slnf_b = p; p = al64(p + E);
+  o->slnf_s = p; p = al64(p + 2);
+  o->s1_w = p; p = al64(p + (long long)d->O * E);
+  o->s1_b = p; p = al64(p + d->O);
+  o->s2_w = p; p = al64(p + (long long)d->CW * d->O);
+  o->s2_b = p; p = al64(p + d->CW);
+  o->total = p;
+  return 0;
+}
+
+// =============================================================================================
+//                                     small helpers
+// =============================================================================================
+struct Carver {
+  unsigned char* base; long long off;
+  template <typename T> T* take(long long n) {
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += ((long long)n * (long long)sizeof(T) + 255) & ~255LL;
+    return p;
+  }
+};
+
+static VgGemmProb mk(const bf16* A, int lda, const bf16* Bm, int ldb, int M, int N, int K) {
+  VgGemmProb p = vg_gemm_prob();
+  p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+// forward Linear: C = act(A W^T + b) (+res)
+static int lin_fwd(const bf16* A, int K, const bf16* W, const float* bias, bf16* C, int M, int N, int act, float ascale,
+                   const bf16* res, bf16* pre_bf16, float* pre_f32, hipStream_t st) {
+  VgGemmProb p = mk(A, K, W, K, M, N, K);
+  p.C = C; p.ldc = N; p.bias = bias; p.act = act; p.act_scale = ascale;
+  p.res = res; p.ldr = N; p.C2 = pre_bf16; p.ldc2 = N;
+  if (pre_f32) { p.pre_f32 = 1; p.Cf = pre_f32; p.ldcf = N; }
+  return vg_gemm_launch(&p, 1, VG_NT, st);
+}
+// dgrad: dX[M,K] = dY[M,N] W[N,K]
+static int lin_dgrad(const bf16* dY, const bf16* W, bf16* dX, int M, int N, int K, int mul, const bf16* Z, const float* Zf,
+                     float ascale, hipStream_t st) {
+  VgGemmProb p = mk(dY, N, W, K, M, K, N);  // GEMM (M x K_out=K) with reduction N
+  p.C = dX; p.ldc = K; p.act = mul; p.act_scale = ascale; p.Z = Z; p.ldz = K; p.Zf = Zf; p.ldzf = K;
+  return vg_gemm_launch(&p, 1, VG_NN, st);
+}
+// wgrad problem: dW[N,K] = dY[M,N]^T X[M,K] -> slab (fp32), k-dimension = M rows
+static VgGemmProb wg(const bf16* dY, int N, const bf16* X, int K, int M, float* slab, long long split_stride, int splits) {
+  VgGemmProb p = mk(dY, N, X, K, N, K, M);
+  p.Cf = slab; p.ldcf = K; p.cf_split_stride = split_stride; p.splits = splits;
+  return p;
+}
+static int pick_splits(long long tiles, int Krows, int cap) {
+  const int ksteps = (Krows + 63) / 64;
+  long long s = (640 + tiles - 1) / tiles;
+  if (s > cap) s = cap;
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+static inline long long tiles128(long long m, long long n) { return ((m + 127) / 128) * ((n + 127) / 128); }
+
+// =============================================================================================
+//                                   ViT (discriminator)
+// =============================================================================================
+#define VIT_SPLIT_CAP 8
+#define EMB_SPLIT_CAP 32
+struct VitWs {
+  bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *z1, *a1, *xcls, *hcls, *th;
+  float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf;
+  bf16 *g[3], *dz1, *dxn, *dao, *dqkv, *gp, *dA, *dzh, *dhcls, *dxcls;
+  float *part, *part_cs, *tok_sum, *slab;
+};
+static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
+  const long long E = d.E, NP = (long long)(d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = (long long)B * S;
+  const long long Kp = (long long)d.C * d.P * d.P, L = d.L, rE = (long long)d.R * E;
+  VgVitLayout lay; vg_vit_layout(&d, &lay);
+  Carver c{(unsigned char*)base, 0};
+  w.Apatch = c.take<bf16>(B * NP * Kp);
+  w.X = c.take<bf16>((L + 1) * M * E);
+  w.xn1 = c.take<bf16>(L * M * E);
+  w.qkv = c.take<bf16>(L * M * 3 * E);
+  w.ao = c.take<bf16>(L * M * E);
+  w.xmid = c.take<bf16>(L * M * E);
+  w.xn2 = c.take<bf16>(L * M * E);
+  w.z1 = c.take<bf16>(L * M * rE);
+  w.a1 = c.take<bf16>(L * M * rE);
+  w.xcls = c.take<bf16>(B * E); w.hcls = c.take<bf16>(B * E); w.th = c.take<bf16>(B * E);
+  w.lse = c.take<float>(L * (long long)B * d.H * S);
+  w.mean1 = c.take<float>(L * M); w.rstd1 = c.take<float>(L * M);
+  w.mean2 = c.take<float>(L * M); w.rstd2 = c.take<float>(L * M);
+  w.meanf = c.take<float>(B); w.rstdf = c.take<float>(B);
+  for (int i = 0; i < 3; ++i) w.g[i] = c.take<bf16>(M * E);
+  w.dz1 = c.take<bf16>(M * rE);
+  w.dxn = c.take<bf16>(M * E);
+  w.dao = c.take<bf16>(M * E);
+  w.dqkv = c.take<bf16>(M * 3 * E);
+  w.gp = c.take<bf16>(B * NP * E);
+  w.dA = c.take<bf16>(B * NP * Kp);
+  w.dzh = c.take<bf16>(B * E); w.dhcls = c.take<bf16>(B * E); w.dxcls = c.take<bf16>(B * E);
+  w.part = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
+  w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)M) * 3 * E);
+  w.tok_sum = c.take<float>(S * E);
+  long long slab = VIT_SPLIT_CAP * lay.layer_weights;
+  if (EMB_SPLIT_CAP * E * Kp > slab) slab = EMB_SPLIT_CAP * E * Kp;
+  w.slab = c.take<float>(slab);
+  return c.off;
+}
+extern "C" long long vg_vit_ws_bytes(const VgVitDims* d, int B) {
+  VgVitLayout lay;
+  if (!d || B < 1 || vg_vit_layout(d, &lay)) return -1;
+  VitWs w;
+  return carve_vit(*d, B, nullptr, w);
+}
+
+extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws, float* logits,
+                              void* stream) {
+  if (!net || !img || !ws || !logits || B < 1) return -1;
+  const VgVitDims& d = net->d;
+  VgVitLayout lay;
+  VG_TRY(vg_vit_layout(&d, &lay));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = d.E, NP = (d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = B * S, Kp = d.C * d.P * d.P, rE = d.R * E;
+  const int HE = E / d.H;
+  VitWs w; carve_vit(d, B, ws, w);
+  const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb;
+  const size_t ME = (size_t)M * E;
+
+  // patch embedding (src/v2/modules.py:82-98): gather -> GEMM(+bias +pos, rows remapped past CLS) ; CLS row
+  VG_TRY(vg_patchify_launch(img, img_is_bf16, w.Apatch, B, d.C, d.IH, d.P, st));
+  {
+    VgGemmProb p = mk(w.Apatch, Kp, Pb + lay.conv_w, Kp, B * NP, E, Kp);
+    p.C = w.X; p.ldc = E; p.bias = P + lay.conv_b; p.resf = P + lay.pos; p.res_period = NP;
+    p.row_in_per = NP; p.row_out_per = S; p.row_out_off = 1;
+    VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
+  }
+  VG_TRY(vg_fill_cls_launch(w.X, P + lay.cls, B, S, E, st));
+
+  for (int l = 0; l < d.L; ++l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* x = w.X + (size_t)l * ME;
+    bf16* xn1 = w.xn1 + (size_t)l * ME;
+    bf16* qkv = w.qkv + (size_t)l * ME * 3;
+    bf16* ao = w.ao + (size_t)l * ME;
+    bf16* xmid = w.xmid + (size_t)l * ME;
+    bf16* xn2 = w.xn2 + (size_t)l * ME;
+    bf16* z1 = w.z1 + (size_t)l * M * rE;
+    bf16* a1 = w.a1 + (size_t)l * M * rE;
+    VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
+                            w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
+    VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st));
+    VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
+                            w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
+    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st));
+    VG_TRY(lin_fwd(a1, rE, Pb + lo + lay.w2, P + lo + lay.b2, w.X + (size_t)(l + 1) * ME, M, E, VG_ACT_NONE, 0.f, xmid,
+                   nullptr, nullptr, st));
+  }
+  // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
+  // classifier (:195): normalise the B CLS rows only.
+  VG_TRY(vg_take_rows_launch(w.X + (size_t)d.L * ME, w.xcls, B, S, 0, 1, E, st));
+  VG_TRY(vg_ln_fwd_launch(w.xcls, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  VG_TRY(lin_fwd(w.hcls, E, Pb + lay.hw1, P + lay.hb1, w.th, B, E, VG_ACT_TANH, 0.f, nullptr, nullptr, nullptr, st));
+  VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
+  return 0;
+}
+
+extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
+                               void* stream) {
+  if (!net || !ws || !dlogits || B < 1) return -1;
+  if (want_wgrad && !net->G) return -1;
+  const VgVitDims& d = net->d;
+  VgVitLayout lay;
+  VG_TRY(vg_vit_layout(&d, &lay));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = d.E, NP = (d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = B * S, Kp = d.C * d.P * d.P, rE = d.R * E;
+  const int HE = E / d.H;
+  VitWs w; carve_vit(d, B, ws, w);
+  const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
+  const size_t ME = (size_t)M * E;
+  const int lnparts = vg_ln_bwd_nparts(M);
+
+  // ---- classifier head + final LN (CLS rows only) ----
+  VG_TRY(vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr,
+                            want_wgrad ? G + lay.hb2 : nullptr, B, E, d.Kc, want_wgrad, st));
+  if (want_wgrad) {
+    VG_TRY(vg_colsum_bf16_launch(w.dzh, E, B, E, w.part_cs, G + lay.hb1, 1, st));
+    VgGemmProb p = wg(w.dzh, E, w.hcls, E, B, w.slab, (long long)E * E, 1);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
+  }
+  VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
+  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, st));
+  if (want_wgrad)
+    VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
+  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
+  VG_TRY(vg_scatter_cls_launch(w.dxcls, g, B, S, E, st));
+  bool have_g_colsum = false;  // part[:, 2E:3E] holds colsum(g) when g came out of an LN backward
+
+  for (int l = d.L - 1; l >= 0; --l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* x = w.X + (size_t)l * ME;
+    const bf16* xn1 = w.xn1 + (size_t)l * ME;
+    const bf16* qkv = w.qkv + (size_t)l * ME * 3;
+    const bf16* ao = w.ao + (size_t)l * ME;
+    const bf16* xmid = w.xmid + (size_t)l * ME;
+    const bf16* xn2 = w.xn2 + (size_t)l * ME;
+    const bf16* z1 = w.z1 + (size_t)l * M * rE;
+    const bf16* a1 = w.a1 + (size_t)l * M * rE;
+    // fc2 bias grad = colsum(g)
+    if (want_wgrad && !have_g_colsum) VG_TRY(vg_colsum_bf16_launch(g, E, M, E, w.part_cs, G + lo + lay.b2, 1, st));
+    // d a1 = g W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
+    VG_TRY(lin_dgrad(g, Pb + lo + lay.w2, w.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
+    if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dz1, rE, M, rE, w.part_cs, G + lo + lay.b1, 1, st));
+    VG_TRY(lin_dgrad(w.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, gmid, w.part, M, E, st));
+    if (want_wgrad)
+      VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0, 1, st));
+    VG_TRY(lin_dgrad(gmid, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, w.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dqkv, 3 * E, M, 3 * E, w.part_cs, G + lo + lay.bqkv, 1, st));
+    VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    if (want_wgrad) {
+      // the four weight gradients of the block as ONE grouped split-K launch (needs g, gmid: before g is recycled)
+      const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
+      const int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
+      VgGemmProb pr[4];
+      pr[0] = wg(w.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
+      pr[1] = wg(gmid, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
+      pr[2] = wg(w.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
+      pr[3] = wg(g, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
+      VG_TRY(vg_gemm_launch(pr, 4, VG_TN, st));
+      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+    }
+    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gin, w.part, M, E, st));
+    if (want_wgrad) {
+      float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
+      VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0, 1, st));
+    }
+    have_g_colsum = true;
+    bf16* t = g; g = gin; gin = t;  // g now = dL/dX[l]
+  }
+
+  // ---- patch embedding ----
+  if (want_wgrad) {
+    VG_TRY(vg_batch_sum_launch(g, w.tok_sum, B, S, E, st));
+    VG_TRY(vg_embed_small_grads_launch(w.tok_sum, G + lay.cls, G + lay.pos, G + lay.conv_b, S, E, st));
+  }
+  if (want_wgrad || d_img) VG_TRY(vg_take_rows_launch(g, w.gp, B, S, 1, NP, E, st));
+  if (want_wgrad) {
+    const int splits = pick_splits(tiles128(E, Kp), B * NP, EMB_SPLIT_CAP);
+    VgGemmProb p = wg(w.gp, E, w.Apatch, Kp, B * NP, w.slab, (long long)E * Kp, splits);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * Kp, p.splits, G + lay.conv_w, (long long)E * Kp, 1, st));
+  }
+  if (d_img) {
+    VG_TRY(lin_dgrad(w.gp, Pb + lay.conv_w, w.dA, B * NP, E, Kp, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_unpatchify_launch(w.dA, (bf16*)d_img, B, d.C, d.IH, d.P, st));
+  }
+  return 0;
+}
+
+// =============================================================================================
+//                                   generator (v1 SLN / SIREN)
+// =============================================================================================
+#define GEN_SPLIT_CAP 8
+struct GenWs {
+  bf16 *zb, *wmod, *s1, *qkv, *cat, *htmp, *s2, *hout, *sf, *y1;
+  float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf, *zf1, *zf2;
+  bf16 *g[3], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
+  float *dw_acc, *part, *part_cs, *emb_sum, *slab;
+};
+static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
+  const long long E = d.E, T = d.T, R = (long long)B * T, L = d.L;
+  VgGenLayout lay; vg_gen_layout(&d, &lay);
+  Carver c{(unsigned char*)base, 0};
+  w.zb = c.take<bf16>((long long)B * d.Z);
+  w.wmod = c.take<bf16>(R * E);
+  w.s1 = c.take<bf16>(L * R * E);
+  w.qkv = c.take<bf16>(L * R * 3 * E);
+  w.cat = c.take<bf16>(L * R * E);
+  w.htmp = c.take<bf16>(L * R * E);
+  w.s2 = c.take<bf16>(L * R * E);
+  w.hout = c.take<bf16>(L * R * E);
+  w.sf = c.take<bf16>(R * E);
+  w.y1 = c.take<bf16>(R * d.O);
+  w.lse = c.take<float>(L * (long long)B * d.H * T);
+  w.mean1 = c.take<float>(L * R); w.rstd1 = c.take<float>(L * R);
+  w.mean2 = c.take<float>(L * R); w.rstd2 = c.take<float>(L * R);
+  w.meanf = c.take<float>(R); w.rstdf = c.take<float>(R);
+  w.zf1 = c.take<float>(R * d.O);
+  w.zf2 = c.take<float>(R * d.CW);
+  for (int i = 0; i < 3; ++i) w.g[i] = c.take<bf16>(R * E);
+  w.dz2 = c.take<bf16>(R * d.CW);
+  w.dz1 = c.take<bf16>(R * d.O);
+  w.ds = c.take<bf16>(R * E);
+  w.dcat = c.take<bf16>(R * E);
+  w.dqkv = c.take<bf16>(R * 3 * E);
+  w.dwb = c.take<bf16>(R * E);
+  w.dw_acc = c.take<float>(R * E);
+  w.part = c.take<float>((long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));
+  w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
+  w.emb_sum = c.take<float>(T * E);
+  long long slab = GEN_SPLIT_CAP * lay.layer_weights;
+  if (T * E * d.Z > slab) slab = T * E * d.Z;
+  if (GEN_SPLIT_CAP * (long long)d.O * E > slab) slab = GEN_SPLIT_CAP * (long long)d.O * E;
+  w.slab = c.take<float>(slab);
+  return c.off;
+}
+extern "C" long long vg_gen_ws_bytes(const VgGenDims* d, int B) {
+  VgGenLayout lay;
+  if (!d || B < 1 || vg_gen_layout(d, &lay)) return -1;
+  GenWs w;
+  return carve_gen(*d, B, nullptr, w);
+}
+
+extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream) {
+  if (!net || !z || !ws || !img || B < 1) return -1;
+  const VgGenDims& d = net->d;
+  VgGenLayout lay;
+  VG_TRY(vg_gen_layout(&d, &lay));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = d.E, T = d.T, R = B * T, HE = E / d.H;
+  GenWs w; carve_gen(d, B, ws, w);
+  const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb;
+  const size_t RE = (size_t)R * E;
+  const float scale = 1.0f / sqrtf((float)E);  // softmax(q.k / sqrt(H*hd)), src/v1/attention.py:51,90
+
+  // mapping network (generator.py:59-61): w = Linear(z) viewed [B*T, E]
+  VG_TRY(vg_cast_f32_bf16_launch(z, w.zb, (long long)B * d.Z, st));
+  VG_TRY(lin_fwd(w.zb, d.Z, Pb + lay.map_w, P + lay.map_b, w.wmod, B, T * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+
+  for (int l = 0; l < d.L; ++l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* h = (l == 0) ? Pb + lay.emb : w.hout + (size_t)(l - 1) * RE;
+    const int hb = (l == 0) ? T : 0;
+    bf16* s1 = w.s1 + (size_t)l * RE;
+    bf16* qkv = w.qkv + (size_t)l * RE * 3;
+    bf16* cat = w.cat + (size_t)l * RE;
+    bf16* htmp = w.htmp + (size_t)l * RE;
+    bf16* s2 = w.s2 + (size_t)l * RE;
+    VG_TRY(vg_sln_fwd_launch(h, hb, w.wmod, P + lo + lay.sln1_w, P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1,
+                             s1, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, R, E, 1e-5f, st));
+    VG_TRY(lin_fwd(s1, E, Pb + lo + lay.wqkv, nullptr, qkv, R, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    VG_TRY(vg_attn_fwd_launch(qkv, cat, w.lse + (size_t)l * B * d.H * T, B, d.H, T, HE, scale, st));
+    {  // htmp = output_linear(cat) + h   (transformer.py:86); block 0 adds the broadcast embedding
+      VgGemmProb p = mk(cat, E, Pb + lo + lay.wo, E, R, E, E);
+      p.C = htmp; p.ldc = E; p.bias = P + lo + lay.bo;
+      if (l == 0) { p.resf = P + lay.emb; p.res_period = T; } else { p.res = h; p.ldr = E; }
+      VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
+    }
+    VG_TRY(vg_sln_fwd_launch(htmp, 0, w.wmod, P + lo + lay.sln2_w, P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1,
+                             s2, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, R, E, 1e-5f, st));
+    VG_TRY(lin_fwd(s2, E, Pb + lo + lay.wm, P + lo + lay.bm, w.hout + (size_t)l * RE, R, E, VG_ACT_NONE, 0.f, htmp, nullptr, nullptr, st));
+  }
+  const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
+  VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
+                           R, E, 1e-5f, st));
+  VG_TRY(lin_fwd(w.sf, E, Pb + lay.s1_w, P + lay.s1_b, w.y1, R, d.O, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf1, st));
+  VG_TRY(lin_fwd(w.y1, d.O, Pb + lay.s2_w, P + lay.s2_b, (bf16*)img, R, d.CW, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf2, st));
+  return 0;
+}
+
+extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream) {
+  if (!net || !ws || !d_img || !net->G || B < 1) return -1;
+  const VgGenDims& d = net->d;
+  VgGenLayout lay;
+  VG_TRY(vg_gen_layout(&d, &lay));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = d.E, T = d.T, R = B * T, HE = E / d.H, PW = 3 * E + 64;
+  GenWs w; carve_gen(d, B, ws, w);
+  const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
+  const size_t RE = (size_t)R * E;
+  const float scale = 1.0f / sqrtf((float)E);
+  const int parts = vg_ln_bwd_nparts(R);
+
+  // SIREN output layers (siren.py:44-45): y = sin(w0 z)  ->  dz = dy * w0 cos(w0 z)
+  VG_TRY(vg_sin_grad_launch((const bf16*)d_img, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
+  VG_TRY(vg_colsum_bf16_launch(w.dz2, d.CW, R, d.CW, w.part_cs, G + lay.s2_b, 1, st));
+  {
+    const int splits = pick_splits(tiles128(d.CW, d.O), R, GEN_SPLIT_CAP);
+    VgGemmProb p = wg(w.dz2, d.CW, w.y1, d.O, R, w.slab, (long long)d.CW * d.O, splits);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.CW * d.O, p.splits, G + lay.s2_w, (long long)d.CW * d.O, 1, st));
+  }
+  VG_TRY(lin_dgrad(w.dz2, Pb + lay.s2_w, w.dz1, R, d.CW, d.O, VG_ACT_MUL_COS, nullptr, w.zf1, d.omega0, st));
+  VG_TRY(vg_colsum_bf16_launch(w.dz1, d.O, R, d.O, w.part_cs, G + lay.s1_b, 1, st));
+  {
+    const int splits = pick_splits(tiles128(d.O, E), R, GEN_SPLIT_CAP);
+    VgGemmProb p = wg(w.dz1, d.O, w.sf, E, R, w.slab, (long long)d.O * E, splits);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.O * E, p.splits, G + lay.s1_w, (long long)d.O * E, 1, st));
+  }
+  VG_TRY(lin_dgrad(w.dz1, Pb + lay.s1_w, w.ds, R, d.O, E, 0, nullptr, nullptr, 0.f, st));
+  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
+  const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
+  VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
+                           nullptr, g, w.dw_acc, 0, w.part, R, E, st));
+  {
+    const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
+    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2, 1, st));
+  }
+  for (int l = d.L - 1; l >= 0; --l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* h = (l == 0) ? Pb + lay.emb : w.hout + (size_t)(l - 1) * RE;
+    const int hb = (l == 0) ? T : 0;
+    const bf16* s1 = w.s1 + (size_t)l * RE;
+    const bf16* qkv = w.qkv + (size_t)l * RE * 3;
+    const bf16* cat = w.cat + (size_t)l * RE;
+    const bf16* htmp = w.htmp + (size_t)l * RE;
+    const bf16* s2 = w.s2 + (size_t)l * RE;
+    // hout = mlp(s2) + htmp  (transformer.py:87; MLP is a single Linear, muilti_layer_perceptron.py:37-42)
+    VG_TRY(lin_dgrad(g, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_sln_bwd_launch(w.ds, htmp, 0, w.wmod, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w,
+                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part, R, E, st));
+    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
+                                G + lo + lay.sln2_s, 2, 1, st));
+    VG_TRY(lin_dgrad(gmid, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, st));
+    VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    {
+      const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);
+      const int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
+      VgGemmProb pr[3];
+      pr[0] = wg(w.dqkv, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
+      pr[1] = wg(gmid, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);
+      pr[2] = wg(g, E, s2, E, R, w.slab + lay.wm, lay.layer_weights, splits);
+      VG_TRY(vg_gemm_launch(pr, 3, VG_TN, st));
+      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+    }
+    VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
+                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part, R, E, st));
+    float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
+    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2, 1, st));
+    bf16* t = g; g = gin; gin = t;
+  }
+  // learned embedding (generator.py:24-26,62) is broadcast over the batch: its gradient is the batch sum
+  VG_TRY(vg_batch_sum_launch(g, w.emb_sum, B, T, E, st));
+  VG_TRY(vg_slab_reduce_launch(w.emb_sum, 0, 1, G + lay.emb, (long long)T * E, 1, st));
+  // mapping Linear: d W = d w^T z ; d b = colsum(d w)   (d w accumulated in fp32 over the 2L+1 SLN uses)
+  VG_TRY(vg_colsum_f32_launch(w.dw_acc, B, T * E, G + lay.map_b, T * E, nullptr, 0, nullptr, 0, nullptr, 0, 1, st));
+  VG_TRY(vg_cast_f32_bf16_launch(w.dw_acc, w.dwb, (long long)R * E, st));
+  {
+    VgGemmProb p = wg(w.dwb, T * E, w.zb, d.Z, B, w.slab, (long long)T * E * d.Z, 1);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)T * E * d.Z, p.splits, G + lay.map_w, (long long)T * E * d.Z, 1, st));
+  }
+  return 0;
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the ViTGAN hot path.
+// Written for wave64 + MFMA 16x16x32 bf16 only; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define VG_WAVE 64
+
+#define VG_CHECK_HIP(expr)                                   \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return (int)_e;                    \
+  } while (0)
+
+__device__ __forceinline__ float vg_bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 vg_f2bf(float v) { return (bf16)v; }
+
+// lane <-> MFMA 16x16x32 bf16 fragment coordinates (cdna_hip_programming.md s3):
+//   A[row = lane&15][k = 8*(lane>>4) + j],  B[k = 8*(lane>>4) + j][col = lane&15],
+//   C/D: col = lane&15, row = 4*(lane>>4) + reg.
+__device__ __forceinline__ f32x4 vg_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a 4x16 block of 16-bit elements,
+// lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i, rows 0..3.
+__device__ __forceinline__ bf16x4 vg_lds_tr_read(const void* lds_ptr) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf4_ptr;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(uintptr_t)(uint32_t)(uintptr_t)lds_ptr);
+}
+
+__device__ __forceinline__ float vg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float vg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float vg_gelu(float x) {  // exact erf form (nn.GELU default)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float vg_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless, so the
+// backward pass regenerates the identical mask from (seed, element index).
+__device__ __forceinline__ uint32_t vg_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}

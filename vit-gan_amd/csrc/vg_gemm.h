@@ -1,0 +1,50 @@
+// Host-side description of one GEMM problem for vg_gemm_launch (internal C++ API).
+#pragma once
+#include "vg_common.h"
+
+// Operand forms.  All matrices are bf16, row-major.
+//   VG_NT : C[m,n] = sum_k A[m,k] * B[n,k]     forward  (x @ W^T, W stored [out,in])
+//   VG_NN : C[m,n] = sum_k A[m,k] * B[k,n]     dgrad    (dy @ W,   W stored [out,in])
+//   VG_TN : C[m,n] = sum_k A[k,m] * B[k,n]     wgrad    (dy^T @ x), split over k, fp32 slabs
+enum { VG_NT = 0, VG_NN = 1, VG_TN = 2 };
+
+enum {
+  VG_ACT_NONE = 0,
+  VG_ACT_GELU = 1,       // exact erf GELU
+  VG_ACT_SIN = 2,        // sin(act_scale * v)         (SIREN)
+  VG_ACT_TANH = 3,
+  VG_ACT_MUL_GELU_GRAD = 4,  // v *= gelu'(Z[m,n])       (fc2 dgrad epilogue)
+  VG_ACT_MUL_COS = 5,        // v *= act_scale*cos(act_scale*Zf[m,n])  (SIREN dgrad epilogue)
+};
+
+struct VgGemmProb {
+  const bf16* A; const bf16* B;
+  int lda, ldb;
+  int M, N, K;
+  int splits;                  // TN only: number of K slices (slab s written at Cf + s*cf_split_stride)
+  bf16* C; int ldc;            // bf16 result (nullable)
+  float* Cf; int ldcf;         // fp32 result: TN slabs, or fp32 pre-activation copy when pre_f32
+  long long cf_split_stride;
+  bf16* C2; int ldc2;          // bf16 pre-activation copy (nullable)
+  const float* bias;           // [N] fp32 (nullable)
+  const bf16* res; int ldr;    // residual added after the activation (nullable)
+  const float* resf; int res_period;  // fp32 addend table [res_period, N] indexed by m % res_period
+  const bf16* Z; int ldz;      // VG_ACT_MUL_GELU_GRAD input
+  const float* Zf; int ldzf;   // VG_ACT_MUL_COS input
+  int act; float act_scale;
+  int pre_f32;                 // store bias-added pre-activation to Cf (fp32) when set (NT only)
+  int row_in_per, row_out_per, row_out_off;  // output row remap: (m/in)*out + off + m%in  (0 = none)
+  // filled by the launcher
+  int tiles_m, tiles_n, tile_start, k_per_split;
+};
+
+#define VG_MAX_GROUP 4
+struct VgGemmGroup {
+  int n;
+  VgGemmProb p[VG_MAX_GROUP];
+};
+
+// Enqueue 1..VG_MAX_GROUP problems of one operand form as a single launch.
+int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream);
+// Convenience: zero-initialised problem.
+static inline VgGemmProb vg_gemm_prob() { VgGemmProb p = {}; p.splits = 1; return p; }

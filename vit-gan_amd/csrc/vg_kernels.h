@@ -1,0 +1,50 @@
+// Internal C++ launch API shared by the engine and the C ABI (all functions only enqueue work).
+#pragma once
+#include "vg_common.h"
+#include "vg_gemm.h"
+
+int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, hipStream_t st);
+int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
+                       int S, int HE, float scale, hipStream_t st);
+
+int vg_ln_fwd_launch(const bf16* x, long long xs, const float* gamma, const float* beta, bf16* y, long long ys,
+                     float* mean, float* rstd, int R, int E, float eps, hipStream_t st);
+int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const float* lw, const float* lb,
+                      const float* gs, const float* bs, bf16* y, float* mean, float* rstd, int R, int E, float eps,
+                      hipStream_t st);
+int vg_ln_bwd_nparts(int R);
+int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
+                     const bf16* gres, bf16* dx, float* part, int R, int E, hipStream_t st);
+int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
+                      const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
+                      const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
+                      hipStream_t st);
+int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
+                         float* d3, int n3, int accumulate, hipStream_t st);
+int vg_colsum_bf16_nparts(int R);
+int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
+                          hipStream_t st);
+
+int vg_patchify_launch(const void* img, int img_is_bf16, bf16* A, int B, int C, int IH, int P, hipStream_t st);
+int vg_unpatchify_launch(const bf16* dA, bf16* dimg, int B, int C, int IH, int P, hipStream_t st);
+int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, hipStream_t st);
+int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int n_take, int E, hipStream_t st);
+int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st);
+int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st);
+int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st);
+int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* logits, int B, int E, int Kc, hipStream_t st);
+int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* dz, float* dW2, float* db2, int B, int E, int Kc,
+                       int want_wgrad, hipStream_t st);
+int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
+                       hipStream_t st);
+int vg_adamw_launch(float* p, const float* g, float* m, float* v, bf16* shadow, long long n, float lr, float b1, float b2,
+                    float eps, float wd, int step, float gscale, hipStream_t st);
+int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_t st);
+int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st);
+int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st);
+
+#define VG_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != 0) return _rc;   \
+  } while (0)
