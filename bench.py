@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""images/sec of the full ViTGAN G+D step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config C2 of BASELINE.json / SURVEY 8): CIFAR-shaped 3x32x32, patch 4 (64+1 tokens), E=384,
+4 heads, 6 blocks discriminator (src/v2) + SLN/SIREN generator (src/v1), per-GPU batch 256, bf16 MFMA
+compute with fp32 accumulation and fp32 master weights, one full alternating step per "step":
+3 D forward + 3 D backward (the third without weight gradients) + G forward + G backward + 2 AdamW.
+Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The reference's algorithm (oracle = fp32 CPU restatement pinned to the reference's outputs) timed
+    on this box's host cores: config C1 (B=64, fp32), same step structure."""
+    import torch
+    from oracle import gen_oracle as go, step_oracle as so, vit_oracle as vo
+
+    B = 64
+    dd, gd = vo.VitDims(classes=1), go.GenDims()
+    oracle = so.GanStepOracle(vo.init_vit_state(dd, 0), go.init_gen_state(gd, 1), dd, gd)
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    z = torch.randn(B, gd.latent, generator=g)
+    oracle.step(real, z)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.step(real, z)
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and (el > seconds_budget or n >= 8):
+            break
+    return {"value": round(n * B / el, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full G+D steps at config C1 (B=64, fp32, torch {torch.__version__} CPU, os.cpu_count={os.cpu_count()})"}
+
+
+def gemm_roofline(torch, B):
+    """Dominant kernel = vg_gemm_kernel<NT> at the QKV-projection shape of the fused real+fake pass
+    (M = 2B*65, N = 1152, K = 384).  Average launch duration measured live with HIP events on the
+    stream the kernel runs on; algorithmic FLOPs = 2*M*N*K."""
+    import ctypes as C
+    from vit_gan_amd import _lib
+    M, N, K = 2 * B * 65, 1152, 384
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.zeros(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.vg_linear_fwd(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), None, None, M, N, K, 0, 0.0, st),
+                   "vg_linear_fwd")
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "kernel": "vg_gemm_kernel<NT> QKV projection", "shape": [M, N, K], "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (C2: 256)")
+    ap.add_argument("--loss", default="ns", choices=["ns", "hinge"])
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph; -1: auto (single GPU only)")
+    ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vit_gan_amd  # noqa: F401
+    from oracle import gen_oracle as go, vit_oracle as vo
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.engine import GanEngine
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    B = args.batch
+    torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
+    cfg = Config(embeddings_dimension=384, attention_heads_count=4, transformer_blocks_count=6, mlp_ratio=2, patch_size=4,
+                 image_size=32, input_channels=3, classes_count=1, dropout_rate=0.0, batch_size=B)
+    D = ViTDiscriminator(cfg).to(dev)
+    G = SirenGenerator().to(dev)
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    reals = [torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
+    torch.manual_seed(4321 + rank)  # noise stream
+
+    for i in range(args.warmup):
+        eng.step(reals[i % 4])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        losses = eng.step(reals[i % 4])
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3
+    t = torch.tensor([max(wall, dev_s)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    lv = losses.cpu().tolist()
+    ok = all(x == x and abs(x) < 1e4 for x in lv)
+
+    if rank == 0:
+        f_d = vo.matmul_flops_per_image(vo.VitDims(classes=1))
+        f_g = go.matmul_flops_per_image(go.GenDims())
+        f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image
+        ips = args.steps * B * world / elapsed
+        step_tf = ips * f_step / 1e12 / world
+        roof = gemm_roofline(torch, B)
+        roof["step_tflops_per_gpu"] = round(step_tf, 1)
+        roof["step_frac_of_peak"] = round(step_tf / PEAK_BF16_TFLOPS, 4)
+        out = {
+            "metric": "images/sec (G+D step) ViTGAN 32x32 patch4 dim384", "value": round(ips, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
+                                   "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
+                       "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": 0.0,
+                       "parallelism": f"dp{world}", "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
+                       "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

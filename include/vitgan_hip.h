@@ -43,7 +43,8 @@ int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* r
                   void* pre_bf16, float* pre_f32, int M, int N, int K, int act, float act_scale,
                   void* stream);
 /* input gradient of nn.Linear:  dX[M,K] = dY[M,N] @ W[N,K]   (autograd of F.linear)
- * mul_mode 0: none; 4: dX *= gelu'(Z) with Z bf16 [M,K]; 5: dX *= s*cos(s*Zf), Zf fp32 [M,K]. */
+ * mul_mode 0: none; 4: dX *= gelu'(Z) with Z bf16 [M,K]; 5: dX *= s*cos(s*Zf), Zf fp32 [M,K];
+ * 6: dX *= 1 - Z^2 (Z = tanh output, bf16 [M,K]). */
 int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode,
                     const void* Z, const float* Zf, float act_scale, void* stream);
 /* weight gradient of nn.Linear:  dW[N,K] (+)= dY[M,N]^T @ X[M,K], computed as `splits` slices of M
@@ -75,6 +76,12 @@ int vg_sln_bwd(const void* dy, const void* h, int h_bcast_rows, const void* w, c
 int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1,
                   float* d2, int n2, float* d3, int n3, int accumulate, void* stream);
 
+/* dst[c] (+)= sum_r X[r][c] for a bf16 matrix (bias gradients: autograd of the "+ bias" in F.linear).
+ * part_ws: vg_colsum_bf16_parts(R) * N floats of scratch.  Deterministic two-stage reduction. */
+int vg_colsum_bf16_parts(int R);
+int vg_colsum_bf16(const void* X, long long ld, int R, int N, float* part_ws, float* dst, int accumulate,
+                   void* stream);
+
 /* Fused multi-head self-attention (src/v2/modules.py:128-159 after the projections; src/v1/attention.py
  * :43-52,:97-101).  qkv bf16 [B*S, 3*H*HE] (Q | K | V thirds, head-major inside each third);
  * out bf16 [B*S, H*HE]; lse fp32 [B,H,S].  softmax(scale * q.k).  HE in {32,64,96}, S <= 80. */
@@ -89,10 +96,12 @@ int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int
                 float grad_scale, void* stream);
 
 /* torch.optim.AdamW step over a flat fp32 buffer (src/v2/training.py:150-157), also refreshing the
- * bf16 shadow the GEMMs read.  n % 4 == 0.  grads are multiplied by gscale first. */
+ * bf16 shadow the GEMMs read.  n % 4 == 0.  grads are multiplied by gscale first.  The step number
+ * (1-based) comes from step_dev[0] (device int) when step_dev != NULL - for hipGraph replay - else
+ * from `step`. */
 int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  float gscale, void* stream);
+                  const int* step_dev, float gscale, void* stream);
 int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

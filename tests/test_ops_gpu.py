@@ -243,7 +243,7 @@ def test_adamw_matches_torch():
         opt.step()
         GR = u.dev(gr * 2.0)
         u.call("vg_adamw_step", u.ptr(P), u.ptr(GR), u.ptr(M_), u.ptr(V_), u.ptr(SH), n, 5e-4, 0.9, 0.999, 1e-8, 1e-3,
-               step, 0.5, u.stream())
+               step, None, 0.5, u.stream())
         u.sync()
         u.assert_close(P, p.detach(), 1e-6, f"adamw step {step}")
         u.assert_close(SH, p.detach(), 2.0 ** -8, "bf16 shadow")

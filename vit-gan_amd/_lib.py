@@ -58,10 +58,12 @@ _SIGNATURES = {
     "vg_sln_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_float, P]),
     "vg_sln_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, P]),
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
+    "vg_colsum_bf16_parts": (c_int, [c_int]),
+    "vg_colsum_bf16": (c_int, [P, c_ll, c_int, c_int, P, P, c_int, P]),
     "vg_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
-    "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "vg_cast_f32_bf16": (c_int, [P, P, c_ll, P]),
     "vg_vit_layout": (c_int, [C.POINTER(VgVitDims), C.POINTER(VgVitLayout)]),
     "vg_vit_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
@@ -91,6 +93,9 @@ def lib() -> C.CDLL:
     """The loaded library; raises loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64; it must be loaded FIRST so that this library binds to the
+        # same HIP runtime instance (same SONAME) - otherwise torch's device pointers are foreign to it.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is the only compute path of this package. "

@@ -18,8 +18,8 @@ extern "C" int vg_linear_fwd(const void* A, const void* W, const float* bias, co
 extern "C" int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode, const void* Z,
                                const float* Zf, float act_scale, void* stream) {
   if (!dY || !W || !dX) return -1;
-  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS) return -4;
-  if ((mul_mode == VG_ACT_MUL_GELU_GRAD && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
+  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS && mul_mode != VG_ACT_MUL_TANH_GRAD) return -4;
+  if (((mul_mode == VG_ACT_MUL_GELU_GRAD || mul_mode == VG_ACT_MUL_TANH_GRAD) && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
   VgGemmProb p = vg_gemm_prob();
   p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = K; p.K = N;
   p.C = (bf16*)dX; p.ldc = K; p.act = mul_mode; p.act_scale = act_scale;
@@ -65,6 +65,11 @@ extern "C" int vg_colsum_f32(const float* part, int rows, int width, float* d0, 
   if (!part || rows < 1 || width < 1) return -1;
   return vg_colsum_f32_launch(part, rows, width, d0, n0, d1, n1, d2, n2, d3, n3, accumulate, (hipStream_t)stream);
 }
+extern "C" int vg_colsum_bf16_parts(int R) { return vg_colsum_bf16_nparts(R); }
+extern "C" int vg_colsum_bf16(const void* X, long long ld, int R, int N, float* part_ws, float* dst, int accumulate, void* stream) {
+  if (!X || !part_ws || !dst) return -1;
+  return vg_colsum_bf16_launch((const bf16*)X, ld, R, N, part_ws, dst, accumulate, (hipStream_t)stream);
+}
 extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;
   return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, (hipStream_t)stream);
@@ -81,9 +86,11 @@ extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out,
   return vg_gan_loss_launch(logits, dlogits, loss_out, n, kind, role, grad_scale, (hipStream_t)stream);
 }
 extern "C" int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, float gscale, void* stream) {
-  if (!p || !g || !m || !v || !shadow_bf16 || n < 1 || step < 1) return -1;
-  return vg_adamw_launch(p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, gscale, (hipStream_t)stream);
+                             float beta2, float eps, float weight_decay, int step, const int* step_dev, float gscale,
+                             void* stream) {
+  if (!p || !g || !m || !v || !shadow_bf16 || n < 1 || (step < 1 && !step_dev)) return -1;
+  return vg_adamw_launch(p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, step_dev, gscale,
+                         (hipStream_t)stream);
 }
 extern "C" int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
   if (!src || !dst_bf16 || n < 1) return -1;

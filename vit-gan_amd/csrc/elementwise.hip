@@ -179,9 +179,14 @@ __global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restric
 __global__ __launch_bounds__(256) void vg_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, bf16* __restrict__ shadow, long long n, float lr,
                                                        float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                       float gscale) {
+                                                       float gscale, const int* __restrict__ step_dev) {
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
+  if (step_dev) {  // step counter kept on the device so a captured hipGraph replays correctly
+    const float t = (float)step_dev[0];
+    bc1 = 1.f - __powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - __powf(b2, t));
+  }
   f32x4 pv = *(f32x4*)(p + i4), gv = *(const f32x4*)(g + i4), mv = *(f32x4*)(m + i4), vv = *(f32x4*)(v + i4);
   bf16x4 sh;
 #pragma unroll
@@ -280,10 +285,10 @@ int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, 
   return (int)hipGetLastError();
 }
 int vg_adamw_launch(float* p, const float* g, float* m, float* v, bf16* shadow, long long n, float lr, float b1, float b2,
-                    float eps, float wd, int step, float gscale, hipStream_t st) {
+                    float eps, float wd, int step, const int* step_dev, float gscale, hipStream_t st) {
   if (n & 3) return -3;
   const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
-  hipLaunchKernelGGL(vg_adamw_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, p, g, m, v, shadow, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+  hipLaunchKernelGGL(vg_adamw_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, p, g, m, v, shadow, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale, step_dev);
   return (int)hipGetLastError();
 }
 int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_t st) {

@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_kernel(const VgGemmGroup grp) 
         const bf16x4 z = *(const bf16x4*)(P.Z + (size_t)m * P.ldz + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= vg_gelu_grad(vg_bf2f(z[r]));
+      } else if (act == VG_ACT_MUL_TANH_GRAD) {
+        const bf16x4 z = *(const bf16x4*)(P.Z + (size_t)m * P.ldz + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float tv = vg_bf2f(z[r]); v[r] *= 1.f - tv * tv; }
       } else if (act == VG_ACT_MUL_COS) {
         const f32x4 z = *(const f32x4*)(P.Zf + (size_t)m * P.ldzf + n);
 #pragma unroll

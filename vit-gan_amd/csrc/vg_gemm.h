@@ -15,6 +15,7 @@ enum {
   VG_ACT_TANH = 3,
   VG_ACT_MUL_GELU_GRAD = 4,  // v *= gelu'(Z[m,n])       (fc2 dgrad epilogue)
   VG_ACT_MUL_COS = 5,        // v *= act_scale*cos(act_scale*Zf[m,n])  (SIREN dgrad epilogue)
+  VG_ACT_MUL_TANH_GRAD = 6,  // v *= 1 - Z[m,n]^2, Z = tanh output  (classifier fc2 dgrad epilogue)
 };
 
 struct VgGemmProb {

@@ -38,7 +38,7 @@ int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* 
 int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
                        hipStream_t st);
 int vg_adamw_launch(float* p, const float* g, float* m, float* v, bf16* shadow, long long n, float lr, float b1, float b2,
-                    float eps, float wd, int step, float gscale, hipStream_t st);
+                    float eps, float wd, int step, const int* step_dev, float gscale, hipStream_t st);
 int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_t st);
 int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st);
 int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st);

@@ -1,0 +1,163 @@
+"""GanEngine: the alternating G/D step (src/v2/training.py:170-211) as a short list of C calls.
+
+One step on each rank (one process per GPU):
+  1. D.grad = 0 ; fake = G(z)                                   (gen forward, saved for step 4)
+  2. D([real ; fake.detach()]) -> loss_real + loss_fake -> backward into D.grad
+     (the reference runs the two halves as separate passes, training.py:182-194; both accumulate
+      into the same .grad before ONE optimizer step and the ViT has no cross-sample op, so running
+      them as one 2B batch is the same computation up to fp32 summation order)
+  3. all-reduce(D.grad) over ranks ; fused AdamW on D            (training.py:197)
+  4. G.grad = 0 ; D(fake) with the UPDATED D -> loss(label = real) -> backward for the input
+     gradient only (D's weight gradients of this pass are discarded by the next zero_grad,
+     training.py:177, so they are never computed) -> gen backward
+  5. all-reduce(G.grad) ; fused AdamW on G                        (training.py:211)
+Nothing synchronises with the host; with ``use_graph`` the whole step is replayed as one hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .generator import SirenGenerator
+from .modules import ViTDiscriminator, VisionTransformer
+
+LOSS_KINDS = {"ns": 0, "hinge": 1}
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class GanEngine:
+    def __init__(self, discriminator, generator: SirenGenerator, batch: int, loss: str = "ns",
+                 lr_d: float = 5e-4, lr_g: float = 5e-4, weight_decay: float = 1e-3, betas=(0.9, 0.999),
+                 eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
+                 process_group: Optional["dist.ProcessGroup"] = None):
+        vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
+        if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
+            raise TypeError("GanEngine needs a ViTDiscriminator/VisionTransformer and a SirenGenerator")
+        self.vit, self.gen = vit, generator
+        self.dev = vit._flat.flat.device
+        if self.dev.type != "cuda" or generator._flat.flat.device != self.dev:
+            raise RuntimeError("GanEngine: both networks must be on the same cuda device (no CPU fallback)")
+        if loss not in LOSS_KINDS:
+            raise ValueError(f"loss must be one of {sorted(LOSS_KINDS)}")
+        self.B, self.kind = int(batch), LOSS_KINDS[loss]
+        self.fuse = bool(fuse_real_fake)
+        self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        d, g = vit._dims, generator._dims
+        if g.T * g.CW != d.C * d.IH * d.IH:
+            raise ValueError("generator output does not match the discriminator's image shape")
+        L = _lib.lib()
+        B, dev = self.B, self.dev
+        nD = 2 * B if self.fuse else B
+        self.Kc = d.Kc
+        self.ws_d = torch.empty(L.vg_vit_ws_bytes(C.byref(d), nD), dtype=torch.uint8, device=dev)
+        self.ws_g = torch.empty(L.vg_gen_ws_bytes(C.byref(g), B), dtype=torch.uint8, device=dev)
+        self.imgs = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)  # [real ; fake]
+        self.dfake = torch.empty(B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)
+        self.logits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
+        self.dlogits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
+        self.z = torch.empty(B, g.Z, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(3, dtype=torch.float32, device=dev)  # d_real, d_fake, g
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        fd, fg = vit._flat, generator._flat
+        self.m_d, self.v_d = torch.zeros_like(fd.flat), torch.zeros_like(fd.flat)
+        self.m_g, self.v_g = torch.zeros_like(fg.flat), torch.zeros_like(fg.flat)
+        fd.refresh_shadow()
+        fg.refresh_shadow()
+        self.steps = 0
+        self._graph = None
+        self._use_graph = bool(use_graph)
+        self._static_real = None
+
+    # ------------------------------------------------------------------------------------------
+    def _nets(self):
+        fd, fg = self.vit._flat, self.gen._flat
+        nd = _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr())
+        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr())
+        return nd, ng
+
+    def _allreduce(self, flat_grad: torch.Tensor) -> None:
+        if self.world > 1:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _adamw(self, fp, m, v, lr, st):
+        h = self.hyp
+        _lib.check(_lib.lib().vg_adamw_step(_p(fp.flat), _p(fp.grad), _p(m), _p(v), _p(fp.shadow), fp.total, lr, h["b1"], h["b2"],
+                                            h["eps"], h["wd"], 0, _p(self.step_t), 1.0 / self.world, st), "vg_adamw_step")
+
+    def _loss(self, lo, n, role, slot, st):
+        L = _lib.lib()
+        off = 4 * lo * self.Kc
+        _lib.check(L.vg_gan_loss(C.c_void_p(self.logits.data_ptr() + off), C.c_void_p(self.dlogits.data_ptr() + off),
+                                 C.c_void_p(self.losses.data_ptr() + 4 * slot), n * self.Kc, self.kind, role, 1.0, st), "vg_gan_loss")
+
+    def _enqueue(self, real: torch.Tensor) -> None:
+        """Enqueue one full step on the current stream (no host sync)."""
+        L, B = _lib.lib(), self.B
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nd, ng = self._nets()
+        fd, fg = self.vit._flat, self.gen._flat
+        img_bytes = self.imgs[0].numel() * 2
+        fake_ptr = C.c_void_p(self.imgs.data_ptr() + B * img_bytes)
+        self.step_t += 1
+        self.imgs[:B].copy_(real)  # fp32 -> bf16 (the GEMM operand type)
+        self.z.normal_()           # construct_noise(), training.py:35-42 / gan.py:231-232
+        fd.grad.zero_()            # gan.discriminator.zero_grad(), training.py:177
+        _lib.check(L.vg_gen_forward(C.byref(ng), B, _p(self.z), _p(self.ws_g), fake_ptr, st), "vg_gen_forward")
+        if self.fuse:
+            _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(self.imgs), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
+            self._loss(0, B, 0, 0, st)
+            self._loss(B, B, 1, 1, st)
+            _lib.check(L.vg_vit_backward(C.byref(nd), 2 * B, _p(self.ws_d), _p(self.dlogits), None, 1, st), "vg_vit_backward")
+        else:
+            for half, role in ((0, 0), (1, 1)):
+                src = C.c_void_p(self.imgs.data_ptr() + half * B * img_bytes)
+                lg = C.c_void_p(self.logits.data_ptr() + 4 * half * B * self.Kc)
+                dl = C.c_void_p(self.dlogits.data_ptr() + 4 * half * B * self.Kc)
+                _lib.check(L.vg_vit_forward(C.byref(nd), B, src, 1, _p(self.ws_d), lg, st), "vg_vit_forward")
+                self._loss(half * B, B, role, role, st)
+                _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), dl, None, 1, st), "vg_vit_backward")
+        self._allreduce(fd.grad)
+        self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st)
+        fg.grad.zero_()            # gan.generator.zero_grad(), training.py:199
+        _lib.check(L.vg_vit_forward(C.byref(nd), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
+        self._loss(0, B, 2, 2, st)
+        _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st), "vg_vit_backward")
+        _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
+        self._allreduce(fg.grad)
+        self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st)
+
+    def step(self, real: torch.Tensor) -> torch.Tensor:
+        """Run one G/D step on ``real`` [B,C,IH,IW] (cuda).  Returns the device tensor
+        [loss_d_real, loss_d_fake, loss_g] of this step without synchronising."""
+        if real.shape[0] != self.B or not real.is_cuda:
+            raise ValueError("real must be a cuda tensor with the engine's batch size")
+        if not (self.vit._flat.aliased() and self.gen._flat.aliased()):
+            raise RuntimeError("module parameters were re-allocated; rebuild the GanEngine")
+        self.steps += 1
+        if not self._use_graph:
+            self._enqueue(real)
+            return self.losses
+        if self._graph is None:
+            self._static_real = real.clone()
+            # warm-up on a side stream (allocator + lazy module state), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._enqueue(self._static_real)
+            torch.cuda.current_stream().wait_stream(s)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._enqueue(self._static_real)
+            self.steps += 1
+        self._static_real.copy_(real)
+        self._graph.replay()
+        return self.losses

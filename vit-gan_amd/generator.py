@@ -1,0 +1,164 @@
+"""The reference's v1 generator (self-modulated LayerNorm blocks + SIREN output) on the HIP engine.
+
+``SirenGenerator`` has the parameter tree - hence the ``state_dict`` keys and shapes - of
+``src.v1.generator.Generator`` (src/v1/generator.py:12-55): mapping Linear(Z -> T*E), learned
+embedding [T,E], L x TransformerSLN (two SLN, H bias-free per-head q/k/v, output Linear, single-Linear
+MLP), final SLN, two SIREN layers; output ``[B, C, IH, IW]`` is the flat view of ``[B, T, C*IW]``.
+Forward/backward are ONE C call each into the fused engine.
+
+Dropout: the reference block applies Dropout(0.2) to the attention output and inside the MLP
+(src/v1/config.py:36,39) in train mode; the fused pass treats them as identity (parity is defined
+in eval mode - RNG streams cannot match).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, flat
+from .flatparams import FlatParams
+
+
+class _Holder(nn.Module):
+    """Parameter container: exists only to give parameters their reference names."""
+
+
+def _linear_holder(out_f, in_f, bias=True):
+    h = _Holder()
+    h.weight = nn.Parameter(torch.empty(out_f, in_f))
+    if bias:
+        h.bias = nn.Parameter(torch.empty(out_f))
+    return h
+
+
+def _mlp_holder(out_f, in_f):  # MLP(...).model = ModuleList([Sequential(Linear, Dropout)])
+    m = _Holder()
+    m.model = nn.ModuleList([nn.Sequential(_linear_holder(out_f, in_f), nn.Identity())])
+    return m
+
+
+def _sln_holder(E):
+    s = _Holder()
+    s.layer_norm = nn.LayerNorm(E)
+    s.beta = nn.Parameter(torch.randn(1, 1, 1))
+    s.gamma = nn.Parameter(torch.randn(1, 1, 1))
+    return s
+
+
+class _GenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: "SirenGenerator", z, anchor):
+        fp = mod._flat
+        fp.refresh_shadow()
+        B = z.shape[0]
+        zin = z.detach().float().contiguous()
+        ws = torch.empty(mod._ws_bytes(B), dtype=torch.uint8, device=z.device)
+        img = torch.empty(B, mod.channels, mod.image_size, mod.image_size, dtype=torch.bfloat16, device=z.device)
+        net = mod._net()
+        _lib.check(_lib.lib().vg_gen_forward(C.byref(net), B, zin.data_ptr(), ws.data_ptr(), img.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vg_gen_forward")
+        ctx.mod, ctx.ws, ctx.B = mod, ws, B
+        return img.to(mod.out_dtype)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        mod = ctx.mod
+        mod._flat.attach_grads()
+        d = dimg.detach().to(torch.bfloat16).contiguous()
+        net = mod._net()
+        _lib.check(_lib.lib().vg_gen_backward(C.byref(net), ctx.B, ctx.ws.data_ptr(), d.data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vg_gen_backward")
+        ctx.ws = None
+        return None, None, None
+
+
+class SirenGenerator(nn.Module):
+    def __init__(self, latent=1024, image_size=32, channels=3, embed=384, heads=4, layers=4, siren_hidden=768,
+                 omega_0=30.0, out_dtype=torch.float32):
+        super().__init__()
+        T, E, hd = image_size, embed, embed // heads
+        self.latent, self.image_size, self.channels, self.out_dtype = latent, image_size, channels, out_dtype
+        self.mapping_mlp = _mlp_holder(T * E, latent)
+        self.embedding = nn.Parameter(torch.randn(T, E))
+        blocks = []
+        for _ in range(layers):
+            b = _Holder()
+            b.layer_norm_1 = _sln_holder(E)
+            b.layer_norm_2 = _sln_holder(E)
+            b.msha = _Holder()
+            heads_l = []
+            for _h in range(heads):
+                a = _Holder()
+                a.q, a.k, a.v = (_linear_holder(hd, E, bias=False) for _ in range(3))
+                heads_l.append(a)
+            b.msha.attention_heads = nn.ModuleList(heads_l)
+            b.msha.output_linear = _linear_holder(E, E)
+            b.mlp = _mlp_holder(E, E)
+            blocks.append(b)
+        self.transformer_layers = nn.ModuleList(blocks)
+        self.sln = _sln_holder(E)
+        s0, s1 = _Holder(), _Holder()
+        s0.linear = _linear_holder(siren_hidden, E)
+        s1.linear = _linear_holder(channels * image_size, siren_hidden)
+        self.output_network = nn.Sequential(s0, s1)
+        self._dims = _lib.VgGenDims(latent, T, E, heads, layers, siren_hidden, channels * image_size, float(omega_0))
+        lay = flat.gen_layout(self._dims)
+        self.reset_parameters()
+        self._flat = FlatParams(dict(self.named_parameters()), flat.gen_slots(self._dims), lay.total)
+
+    def reset_parameters(self):
+        """Init distributions of the reference: nn.Linear default U(+-1/sqrt(in)); SIREN U(+-1/in) for
+        the first layer and U(+-sqrt(6/in)/omega0) after (src/v1/siren.py:29-42); embedding, gamma,
+        beta ~ N(0,1) (generator.py:24-26, spectral_layer_norm.py:16-17)."""
+        w0 = float(self._dims.omega0)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name == "embedding" or name.endswith((".beta", ".gamma")):
+                    p.normal_()
+                elif "layer_norm.weight" in name:
+                    p.fill_(1.0)
+                elif "layer_norm.bias" in name:
+                    p.zero_()
+                elif name == "output_network.0.linear.weight":
+                    p.uniform_(-1.0 / p.shape[1], 1.0 / p.shape[1])
+                elif name == "output_network.1.linear.weight":
+                    b = math.sqrt(6.0 / p.shape[1]) / w0
+                    p.uniform_(-b, b)
+                elif name.endswith("weight"):
+                    b = 1.0 / math.sqrt(p.shape[1])
+                    p.uniform_(-b, b)
+                else:  # Linear bias: bound from the fan-in of its weight
+                    fan_in = dict(self.named_parameters())[name[:-4] + "weight"].shape[1]
+                    b = 1.0 / math.sqrt(fan_in)
+                    p.uniform_(-b, b)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_flat"):
+            self._flat.named = dict(self.named_parameters())
+            self._flat.rebuild()
+        return out
+
+    def zero_grad(self, set_to_none: bool = True):
+        self._flat.zero_grad()
+
+    def _ws_bytes(self, B):
+        n = _lib.lib().vg_gen_ws_bytes(C.byref(self._dims), B)
+        if n <= 0:
+            raise RuntimeError("vg_gen_ws_bytes failed")
+        return n
+
+    def _net(self):
+        fp = self._flat
+        return _lib.VgGenNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr())
+
+    def forward(self, z):
+        if not z.is_cuda:
+            raise RuntimeError("SirenGenerator.forward: the HIP engine needs cuda tensors; there is no CPU fallback")
+        if not self._flat.aliased():
+            self._flat.named = dict(self.named_parameters())
+            self._flat.rebuild()
+        return _GenFn.apply(self, z, self.embedding)
