@@ -72,18 +72,29 @@ __global__ __launch_bounds__(256) void vg_scatter_cls_kernel(const bf16* __restr
   if (s == 0) v = *(const u32x4*)(src + (size_t)b * E + 8 * c);
   *(u32x4*)(g + (size_t)r * E + 8 * c) = v;
 }
-// out[s, e] = sum_b g[(b*S + s), e]   (fp32, one thread per (s, e) pair of columns)
+// out[s, e] = sum_b g[(b*S + s), e]   (fp32; 32 column pairs x 8 batch-lanes per workgroup, fixed fold order)
 __global__ __launch_bounds__(256) void vg_batch_sum_kernel(const bf16* __restrict__ g, float* __restrict__ out, int B, int S,
                                                            int E) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= S * (E / 2)) return;
-  const int s = i / (E / 2), e = 2 * (i - s * (E / 2));
+  __shared__ float red[8][66];
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;  // column-pair index over S*E/2
+  const int total = S * (E / 2);
   float a0 = 0.f, a1 = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const bf16x2 t = *(const bf16x2*)(g + ((size_t)b * S + s) * E + e);
-    a0 += vg_bf2f(t[0]); a1 += vg_bf2f(t[1]);
+  int s = 0, e = 0;
+  if (i < total) {
+    s = i / (E / 2); e = 2 * (i - s * (E / 2));
+    for (int b = bl; b < B; b += 8) {
+      const bf16x2 t = *(const bf16x2*)(g + ((size_t)b * S + s) * E + e);
+      a0 += vg_bf2f(t[0]); a1 += vg_bf2f(t[1]);
+    }
   }
-  out[(size_t)s * E + e] = a0; out[(size_t)s * E + e + 1] = a1;
+  red[bl][2 * cl] = a0; red[bl][2 * cl + 1] = a1;
+  __syncthreads();
+  if (bl != 0 || i >= total) return;
+  float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { r0 += red[k][2 * cl]; r1 += red[k][2 * cl + 1]; }
+  out[(size_t)s * E + e] = r0; out[(size_t)s * E + e + 1] = r1;
 }
 // embed grads from tok_sum [S,E]: d_cls += tok_sum[0]; d_pos += tok_sum[1:]; d_convbias += sum_n tok_sum[1+n]
 __global__ __launch_bounds__(256) void vg_embed_small_grads_kernel(const float* __restrict__ tok_sum, float* __restrict__ d_cls,
@@ -125,21 +136,21 @@ __global__ __launch_bounds__(256) void vg_head_bwd_dz_kernel(const float* __rest
   const float tv = vg_bf2f(t[i]);
   dz[i] = vg_f2bf(a * (1.f - tv * tv));
 }
-// dW2[k,e] += sum_b dlog[b,k] t[b,e];  db2[k] += sum_b dlog[b,k]
+// dW2[k,e] += sum_b dlog[b,k] t[b,e];  db2[k] += sum_b dlog[b,k]      (one wave per (k, e); lanes over b)
 __global__ __launch_bounds__(256) void vg_head_bwd_w2_kernel(const float* __restrict__ dlog, const bf16* __restrict__ t,
                                                              float* __restrict__ dW2, float* __restrict__ db2, int B, int E,
                                                              int Kc) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Kc * (E + 1)) return;
-  const int k = i / (E + 1), e = i - k * (E + 1);
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= Kc * (E + 1)) return;
+  const int k = wv / (E + 1), e = wv - k * (E + 1);
   float a = 0.f;
   if (e < E) {
-    for (int b = 0; b < B; ++b) a += dlog[b * Kc + k] * vg_bf2f(t[(size_t)b * E + e]);
-    dW2[(size_t)k * E + e] += a;
+    for (int b = lane; b < B; b += 64) a += dlog[b * Kc + k] * vg_bf2f(t[(size_t)b * E + e]);
   } else {
-    for (int b = 0; b < B; ++b) a += dlog[b * Kc + k];
-    db2[k] += a;
+    for (int b = lane; b < B; b += 64) a += dlog[b * Kc + k];
   }
+  a = vg_wave_sum(a);
+  if (lane == 0) { if (e < E) dW2[(size_t)k * E + e] += a; else db2[k] += a; }
 }
 
 // ---- GAN losses on logits [n] ------------------------------------------------------------------
@@ -260,7 +271,7 @@ int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStre
   return (int)hipGetLastError();
 }
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st) {
-  hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(nblk((long long)S * (E / 2))), dim3(256), 0, st, g, out, B, S, E);
+  hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(nblk((long long)S * (E / 2), 32)), dim3(256), 0, st, g, out, B, S, E);
   return (int)hipGetLastError();
 }
 int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st) {
@@ -275,7 +286,7 @@ int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* 
                        int want_wgrad, hipStream_t st) {
   hipLaunchKernelGGL(vg_head_bwd_dz_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, dlog, W2, t, dz, B, E, Kc);
   if (want_wgrad)
-    hipLaunchKernelGGL(vg_head_bwd_w2_kernel, dim3(nblk((long long)Kc * (E + 1))), dim3(256), 0, st, dlog, t, dW2, db2, B, E, Kc);
+    hipLaunchKernelGGL(vg_head_bwd_w2_kernel, dim3(nblk((long long)Kc * (E + 1), 4)), dim3(256), 0, st, dlog, t, dW2, db2, B, E, Kc);
   return (int)hipGetLastError();
 }
 int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,

@@ -7,7 +7,7 @@
 #include "vg_common.h"
 
 #define LN_MAX_PER_LANE 16  // E <= 1024
-#define LN_ROWS_PER_WG 32   // 4 waves x 8 rows
+#define LN_MAX_PARTS 512    // partial rows written by the backward kernels (fixed upper bound)
 
 // ------------------------------------------------------------------------------------------
 // y = LN(x) * gamma + beta ; stats saved for backward.  Row r of x at x + r*xs (elements).
@@ -127,10 +127,9 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
   for (int i = 0; i < LN_MAX_PER_LANE; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
   float s_gs = 0.f, s_bs = 0.f;
   const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
-  const int row0 = blockIdx.x * LN_ROWS_PER_WG + w * (LN_ROWS_PER_WG / 4);
-  for (int rr = 0; rr < LN_ROWS_PER_WG / 4; ++rr) {
-    const int row = row0 + rr;
-    if (row >= R) break;
+  // rows are dealt to (workgroup, wave) pairs round-robin: wave w of block b takes rows
+  // 4*b + w, 4*b + w + 4*gridDim.x, ...  (fixed assignment -> deterministic partial sums)
+  for (int row = blockIdx.x * 4 + w; row < R; row += 4 * gridDim.x) {
     const int xrow = x_bcast_rows > 0 ? row % x_bcast_rows : row;
     const bf16x2* xr = (const bf16x2*)(x + (size_t)xrow * E);
     const bf16x2* dr = (const bf16x2*)(dy + (size_t)row * E);
@@ -216,8 +215,16 @@ struct VgSeg { float* dst; int n; };
 struct VgSegs { VgSeg s[4]; };
 __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restrict__ part, int rows, int width,
                                                             VgSegs segs, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= width) return;
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a = 0.f;
+  if (c < width)
+    for (int r = rl; r < rows; r += 8) a += part[(size_t)r * width + c];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl != 0 || c >= width) return;
+  a = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
   int off = 0; float* dst = nullptr;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -225,8 +232,6 @@ __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restr
     off += segs.s[k].n;
   }
   if (!dst) return;
-  float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += part[(size_t)r * width + c];
   if (accumulate) *dst += a; else *dst = a;
 }
 
@@ -260,7 +265,7 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
                      mean, rstd, R, E, eps);
   return (int)hipGetLastError();
 }
-int vg_ln_bwd_nparts(int R) { return (R + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG; }
+int vg_ln_bwd_nparts(int R) { const int n = (R + 7) / 8; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, hipStream_t st) {
   if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
@@ -281,18 +286,19 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
 int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
                          float* d3, int n3, int accumulate, hipStream_t st) {
   VgSegs s; s.s[0] = {d0, n0}; s.s[1] = {d1, n1}; s.s[2] = {d2, n2}; s.s[3] = {d3, n3};
-  hipLaunchKernelGGL(vg_colsum_f32_kernel, dim3((width + 255) / 256), dim3(256), 0, st, part, rows, width, s, accumulate);
+  hipLaunchKernelGGL(vg_colsum_f32_kernel, dim3((width + 31) / 32), dim3(256), 0, st, part, rows, width, s, accumulate);
   return (int)hipGetLastError();
 }
-#define COLSUM_ROWS 128
-int vg_colsum_bf16_nparts(int R) { return (R + COLSUM_ROWS - 1) / COLSUM_ROWS; }
+#define COLSUM_MAX_CHUNKS 128
+static inline int colsum_rows(int R) { int r = (R + COLSUM_MAX_CHUNKS - 1) / COLSUM_MAX_CHUNKS; return r < 32 ? 32 : r; }
+int vg_colsum_bf16_nparts(int R) { const int r = colsum_rows(R); return (R + r - 1) / r; }
 // dst[c] (+)= sum_r X[r][c]; `part` needs vg_colsum_bf16_nparts(R) * N floats of scratch.
 int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
                           hipStream_t st) {
   if ((N & 1) || R < 1) return -3;
   const int chunks = vg_colsum_bf16_nparts(R);
   hipLaunchKernelGGL(vg_colsum_bf16_part_kernel, dim3((N / 2 + 255) / 256, chunks), dim3(256), 0, st, X, ld, R, N,
-                     COLSUM_ROWS, part);
+                     colsum_rows(R), part);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   return vg_colsum_f32_launch(part, chunks, N, dst, N, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, st);
