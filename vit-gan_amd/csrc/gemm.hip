@@ -1,80 +1,98 @@
 // bf16 MFMA GEMM family for the ViTGAN hot path (gfx950).
 //
-// One kernel template, three operand forms (vg_gemm.h).  Tile 128(m) x 128(n) x 64(k),
+// One kernel template, three operand forms (vg_gemm.h).  Tile 128(m) x 128(n) x 32(k),
 // 256 threads = 4 waves as 2(m) x 2(n), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
-// LDS: two stages x (16 KiB + 16 KiB), register-staged with the loads of step t+1 issued
-// before the MFMAs of step t and written to the other stage afterwards (one barrier/step).
+// LDS: a 4-stage ring of (8 KiB + 8 KiB) filled by LDS-DMA (global_load_lds_dwordx4); three
+// k-steps stay in flight across a raw s_barrier behind a COUNTED s_waitcnt vmcnt, because with
+// K = 384..1152 the kernel is L2-latency bound, not MFMA bound (2 workgroups/CU x 48 KiB in flight).
 //
 // The MFMA is issued "swapped": its A operand carries the GEMM's n index and its B operand the
 // m index, so a lane's 4 accumulator registers are 4 CONSECUTIVE n of one output row m and the
 // epilogue stores 8 B (bf16) / 16 B (fp32) per lane straight from registers.
 //
 // Operand images in LDS:
-//   row form  [128 rows][64 k]  (128-B rows): 16-B chunk c of row r lives at chunk c ^ (r & 7);
-//             fragments by ds_read_b128.
-//   tr  form  [64 k][128 cols]  (256-B rows): 16-B chunk c of row k lives at c ^ (2*sigma(k)),
+//   row form  [128 rows][32 k]  (64-B rows): 16-B chunk c of row r lives at chunk c ^ F[(r>>2)&3],
+//             F = {0,2,3,1}: the four 16-lane groups of a ds_read_b128 then each cover all 16
+//             slots of a 256-B bank row (conflict-free).
+//   tr  form  [32 k][128 cols]  (256-B rows): 16-B chunk c of row k lives at c ^ (2*sigma(k)),
 //             sigma(k) = (k&3) | ((k>>3)&1)<<2; fragments by two ds_read_b64_tr_b16, whose 32-lane
 //             halves then touch all 64 banks exactly once.
 #include "vg_gemm.h"
+#include <stdlib.h>
 
-#define BM 128
+#define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
-#define BK 64
-#define STAGE_BYTES 32768
-#define TILE_BYTES 16384
+#define BK 32
+#define NSTAGE 4            // LDS ring: 3 k-steps in flight behind a counted vmcnt + 1 being read
+#define A_TILE_BYTES (BM * BK * 2)
+#define B_TILE_BYTES 8192
+#define STAGE_BYTES (A_TILE_BYTES + B_TILE_BYTES)
 
 __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
 
-// ---- global -> registers ---------------------------------------------------------------
-template <bool TR>
-__device__ __forceinline__ void stage_load(u32x4 (&reg)[4], const bf16* __restrict__ X, int ld,
-                                           int idx0, int idx_end, int k0, int k_end, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (!TR) {
-      const int row = idx0 + (id >> 3), k = k0 + ((id & 7) << 3);
-      if (row < idx_end && k < k_end) v = *(const u32x4*)(X + (size_t)row * ld + k);
-    } else {
-      const int k = k0 + (id >> 4), col = idx0 + ((id & 15) << 3);
-      if (k < k_end && col < idx_end) v = *(const u32x4*)(X + (size_t)k * ld + col);
-    }
-    reg[i] = v;
-  }
-}
+// ---- global -> LDS, direct (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave-instruction) ----
+// The LDS destination of one instruction is wave-uniform base + lane*16, so the tile images are
+// lane-linear per 1-KiB piece and the XOR swizzle is applied to the per-lane SOURCE address
+// (cdna_hip_programming.md rule 21).  A tile is 16 pieces; wave w issues pieces w, w+4, w+8, w+12.
+// Out-of-range lanes read 16 zero bytes from `zeros` instead (keeps the LDS image finite).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-// ---- registers -> LDS --------------------------------------------------------------------
-template <bool TR>
-__device__ __forceinline__ void stage_write(const u32x4 (&reg)[4], unsigned char* tile, int tid) {
+__device__ __forceinline__ int row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }  // {0,2,3,1}
+
+// PIECES 1-KiB pieces per tile (8 per 128 rows/cols), dealt round-robin to the NW waves.
+// The per-lane source pointer of every piece is computed ONCE per tile (`setup`); a k-step then only
+// advances it, so issuing a piece costs a couple of VALU ops next to the DMA instruction itself.
+template <bool TR, int PIECES, int NW>
+struct Stager {
+  static constexpr int PER = PIECES / NW;
+  const bf16* src[PER];   // per-lane pointer at k = 0 of this tile, nullptr when the lane's row/column is out of range
+  int kc[PER];            // row form: lane's k offset inside a step (elements); tr form: lane's k row inside a step
+  long long kstride;      // elements to advance per unit of k (1 for row form, ld for tr form)
+
+  __device__ __forceinline__ void setup(const bf16* __restrict__ X, int ld, int idx0, int idx_end, int wid, int lane) {
+    kstride = TR ? ld : 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i;
-    int off;
-    if (!TR) {
-      const int row = id >> 3, c = id & 7;
-      off = row * 128 + ((c ^ (row & 7)) << 4);
-    } else {
-      const int kk = id >> 4, c = id & 15;
-      off = kk * 256 + ((c ^ (2 * tr_sigma(kk))) << 4);
+    for (int i = 0; i < PER; ++i) {
+      const int j = wid + NW * i;
+      if (!TR) {  // piece = 16 rows x 64 B
+        const int rl = 16 * j + (lane >> 2);
+        const int row = idx0 + rl;
+        kc[i] = ((lane & 3) ^ row_f(rl)) << 3;
+        src[i] = (row < idx_end) ? X + (size_t)row * ld + kc[i] : nullptr;
+      } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 pieces per sub-tile)
+        const int sub = j >> 3, jj = j & 7;
+        const int kk = 4 * jj + (lane >> 4);
+        const int c = (lane & 15) ^ (2 * tr_sigma(kk));
+        const int col = idx0 + 128 * sub + (c << 3);
+        kc[i] = kk;
+        src[i] = (col < idx_end) ? X + (size_t)kk * ld + col : nullptr;
+      }
     }
-    *(u32x4*)(tile + off) = reg[i];
   }
-}
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int k_end, const void* zeros, int wid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = wid + NW * i;
+      const void* p = (src[i] != nullptr && k0 + kc[i] < k_end) ? (const void*)(src[i] + (long long)k0 * kstride) : zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(tile + 1024 * j), 16, 0, 0);
+    }
+  }
+};
 
 // ---- LDS -> MFMA fragment: 16 rows/cols starting at i0, k sub-step ks (32 wide) -------------
 template <bool TR>
-__device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, int ks, int lane) {
+__device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, int lane) {
   const int g = lane >> 4, li = lane & 15;
   if (!TR) {
-    const int row = i0 + li, c = 4 * ks + g;
-    return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+    const int row = i0 + li;
+    return *(const bf16x8*)(tile + row * 64 + ((g ^ row_f(row)) << 4));
   } else {
     const int q = li >> 2, p = li & 3;
-    const int c8 = (i0 >> 2) + p;
+    const int c8 = ((i0 & 127) >> 2) + p;
     const int sw = 2 * (q | ((g & 1) << 2));
-    const int kk0 = 32 * ks + 8 * g + q;
-    const unsigned char* a0 = tile + kk0 * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);
+    const int kk0 = 8 * g + q;
+    const unsigned char* a0 = tile + (i0 >> 7) * 8192 + kk0 * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);
     typedef bf16x4 __attribute__((address_space(3))) * lds4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + 4 * 256));
@@ -85,20 +103,24 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, i
   }
 }
 
-__device__ __forceinline__ float apply_act(int act, float scale, float v) {
-  switch (act) {
-    case VG_ACT_GELU: return vg_gelu(v);
-    case VG_ACT_SIN: return __sinf(scale * v);
-    case VG_ACT_TANH: return tanhf(v);
-    default: return v;
-  }
+template <int ACT>
+__device__ __forceinline__ float apply_act(float scale, float v) {
+  if (ACT == VG_ACT_GELU) return vg_gelu(v);
+  if (ACT == VG_ACT_SIN) return __sinf(scale * v);
+  if (ACT == VG_ACT_TANH) return vg_tanh(v);
+  return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void vg_gemm_kernel(const VgGemmGroup grp) {
+// FEAT: epilogue features COMPILED IN (each still tests its runtime pointer); the launcher picks the
+// smallest compiled superset so the common epilogues carry no dead address arithmetic.
+enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31 };
+
+template <int MODE, int WM, int ACT, int FEAT>
+__global__ __launch_bounds__(128 * WM) void vg_gemm_kernel(const VgGemmGroup grp) {
+  constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE_BYTES];
 
   // XCD-aware block order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
   // run of tiles so the n-tiles of one m-panel hit the same L2 (bijective for any grid size).
@@ -113,6 +135,18 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_kernel(const VgGemmGroup grp) 
   for (int i = 1; i < VG_MAX_GROUP; ++i)
     if (i < grp.n && bid >= grp.p[i].tile_start) pi = i;
   const VgGemmProb& P = grp.p[pi];
+  // epilogue operands, read from kernarg memory up front (overlaps the prologue DMA latency)
+  const int eM = P.M, eN = P.N;
+  bf16* const eC = P.C; const int eldc = P.ldc;
+  bf16* const eC2 = P.C2; const int eldc2 = P.ldc2;
+  float* const eCf = P.Cf; const int eldcf = P.ldcf; const long long ecfs = P.cf_split_stride;
+  const float* const ebias = P.bias;
+  const bf16* const eres = P.res; const int eldr = P.ldr;
+  const float* const eresf = P.resf; const int eper = P.res_period;
+  const bf16* const eZ = P.Z; const int eldz = P.ldz;
+  const float* const eZf = P.Zf; const int eldzf = P.ldzf;
+  const float ascale = P.act_scale;
+  const int epre = P.pre_f32, rip = P.row_in_per, rop = P.row_out_per, roo = P.row_out_off;
 
   const int local = bid - P.tile_start;
   const int tiles_mn = P.tiles_m * P.tiles_n;
@@ -124,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_kernel(const VgGemmGroup grp) 
   const int k_end = min(P.K, k_begin + P.k_per_split);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
   const int g = lane >> 4, li = lane & 15;
 
   f32x4 acc[4][4];  // [nt][mt]
@@ -137,122 +171,230 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_kernel(const VgGemmGroup grp) 
   const bf16* __restrict__ Bg = P.B;
   const int lda = P.lda, ldb = P.ldb;
   // row form indexes rows (m or n) against M/N; tr form indexes columns against M/N.
-  u32x4 ra[4], rb[4];
+  const void* zeros = grp.zeros;
+#ifdef VG_STAMPS
+  unsigned long long tstamp[8];
+  tstamp[0] = __builtin_amdgcn_s_memrealtime();
+#define STAMP(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define STAMP(i)
+#endif
   const int nsteps = (k_end - k_begin + BK - 1) / BK;
-  if (nsteps > 0) {
-    stage_load<A_TR>(ra, Ag, lda, m0, P.M, k_begin, k_end, tid);
-    stage_load<B_TR>(rb, Bg, ldb, n0, P.N, k_begin, k_end, tid);
-    stage_write<A_TR>(ra, smem, tid);
-    stage_write<B_TR>(rb, smem + TILE_BYTES, tid);
-  }
-  __syncthreads();
+  Stager<A_TR, 4 * WM, NW> sa;
+  Stager<B_TR, 8, NW> sb;
+  sa.setup(Ag, lda, m0, P.M, wid, lane);
+  sb.setup(Bg, ldb, n0, P.N, wid, lane);
+#define ISSUE(step)                                                                                      \
+  do {                                                                                                   \
+    unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
+    const int _k0 = k_begin + (step) * BK;                                                               \
+    sa.issue(_b, _k0, k_end, zeros, wid);                                                                \
+    sb.issue(_b + A_TILE_BYTES, _k0, k_end, zeros, wid);                                                 \
+  } while (0)
+  // Per k-step: counted vmcnt (stage s landed; s+1, s+2 may still fly) -> s_barrier -> DMA for s+3 ->
+  // ds_read fragments -> 16 MFMAs.  With 2 workgroups per CU the other workgroup's waves fill the
+  // SIMD while this one waits.  (A register-double-buffered variant that read step s+1's fragments
+  // under step s's MFMAs measured no faster on MI355X - LDS bandwidth, not latency, is the co-limit.)
+  constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
+  STAMP(1);
+  for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
+  STAMP(2);
+#pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
-    unsigned char* cur = smem + (s & 1) * STAGE_BYTES;
-    unsigned char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
-    const bool more = (s + 1 < nsteps);
-    if (more) {
-      const int k0 = k_begin + (s + 1) * BK;
-      stage_load<A_TR>(ra, Ag, lda, m0, P.M, k0, k_end, tid);
-      stage_load<B_TR>(rb, Bg, ldb, n0, P.N, k0, k_end, tid);
+    const int ahead = nsteps - 1 - s;  // stages issued after s
+    if (ahead >= 2) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); }
+    else if (ahead == 1) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef VG_STAMPS
+    if (s == 0) STAMP(3);
+#endif
+    if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1);
+    const unsigned char* cur = smem + (s % NSTAGE) * STAGE_BYTES;
+    bf16x8 fm[4], fn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane);
+      fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fm[4], fn[4];
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, ks, lane);
-        fn[i] = load_frag<B_TR>(cur + TILE_BYTES, wn * 64 + i * 16, ks, lane);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
-    }
-    if (more) {
-      stage_write<A_TR>(ra, nxt, tid);
-      stage_write<B_TR>(rb, nxt + TILE_BYTES, tid);
-    }
-    __syncthreads();
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
   }
+#undef ISSUE
 
-  // ---- epilogue: lane owns row m (per mt) and 4 consecutive n (per nt) ----------------------
-  const int act = P.act;
-  const float ascale = P.act_scale;
+  // ---- epilogue ---------------------------------------------------------------------------
+  // Accumulators (lane = one row, 4 consecutive n per tile) are transposed through a PRIVATE per-wave
+  // LDS region (32 rows x 64 fp32, 272-B row pitch: conflict-free 16-B writes) so that each lane
+  // then owns 8 consecutive columns of one row and every global access is 16 B per lane with
+  // whole 128-B lines per wave-instruction (per-lane stores at a row stride are issue-bound).
+  // Problem fields are copied to registers first (a reference into kernarg memory is re-read after
+  // every store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt
+  // retires in order, so a load issued behind stores would wait for them.
+  STAMP(4);
+  __syncthreads();  // every wave is done reading the operand ring
+  STAMP(5);
+  unsigned char* creg = smem + wid * (32 * 272);
+  const int er = lane >> 3, ec = lane & 7;  // read-back: 8 rows x 8 column-chunks per pass
+  const int n = n0 + wn * 64 + ec * 8;
+  const bool ncol_ok = n < eN;
+  const int mrow0 = m0 + wm * 64 + er;  // slot q (= 4*half + it) covers tile row mrow0 + 8*q
+  constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD);
+  constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
+  constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
+  constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0;
+  constexpr bool PRE_BF = NEED_ZBF || HAS_RES, PRE_F = NEED_ZF || HAS_RESF;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  bf16x8 pre_bf[PRE_BF ? 8 : 1];
+  f32x4 pre_f0[PRE_F ? 8 : 1], pre_f1[PRE_F ? 8 : 1];
+  auto out_row = [&](int m) -> int {
+    if (HAS_REMAP && rip > 0) return (m / rip) * rop + roo + (m % rip);
+    return m;
+  };
+  if (MODE != VG_TN) {
+    if (ebias && ncol_ok) { b0 = *(const f32x4*)(ebias + n); b1 = *(const f32x4*)(ebias + n + 4); }
+    if (PRE_BF || PRE_F) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + li;
-    if (m >= P.M) continue;
-    int mo = m;
-    if (P.row_in_per > 0) mo = (m / P.row_in_per) * P.row_out_per + P.row_out_off + (m % P.row_in_per);
+      for (int q = 0; q < 8; ++q) {
+        const int m = mrow0 + 8 * q;
+        const bool ok = ncol_ok && m < eM;
+        if (PRE_BF) {
+          bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
+          else if (eres && ok) zb = *(const bf16x8*)(eres + (unsigned)(out_row(m) * eldr + n));
+          pre_bf[q] = zb;
+        }
+        if (PRE_F) {
+          f32x4 zf0 = {0.f, 0.f, 0.f, 0.f}, zf1 = zf0;
+          if (NEED_ZF) { if (ok) { const float* zp = eZf + (unsigned)(m * eldzf + n); zf0 = *(const f32x4*)zp; zf1 = *(const f32x4*)(zp + 4); } }
+          else if (eresf && ok) { const float* rp = eresf + (unsigned)((m % eper) * eN + n); zf0 = *(const f32x4*)rp; zf1 = *(const f32x4*)(rp + 4); }
+          pre_f0[q] = zf0; pre_f1[q] = zf1;
+        }
+      }
+    }
+  }
+  STAMP(6);
+  // phase 1: all LDS traffic (the compiler fences every ds_read behind vmcnt(0) once LDS-DMA has been
+  // used, so no global store may be in flight yet); phase 2: arithmetic + global stores.
+  f32x4 tlo[8], thi[8];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-      if (n >= P.N) continue;
-      f32x4 v = acc[nt][mt];
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      const int mt = 2 * half + mh;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *(f32x4*)(creg + (mh * 16 + li) * 272 + (nt * 16 + 4 * g) * 4) = acc[nt][mt];
+    }
+    // same wave reads back what it wrote: LDS ops of one wave complete in order
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const unsigned char* rp = creg + (it * 8 + er) * 272 + ec * 32;
+      tlo[4 * half + it] = *(const f32x4*)rp;
+      thi[4 * half + it] = *(const f32x4*)(rp + 16);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    {
+      const int m = mrow0 + 8 * q;
+      const f32x4 lo = tlo[q], hi = thi[q];
+      if (m >= eM || !ncol_ok) continue;
       if (MODE == VG_TN) {
-        *(f32x4*)(P.Cf + (size_t)split * P.cf_split_stride + (size_t)m * P.ldcf + n) = v;
+        float* dst = eCf + (size_t)split * ecfs + (unsigned)(m * eldcf + n);
+        *(f32x4*)dst = lo;
+        *(f32x4*)(dst + 4) = hi;
         continue;
       }
-      if (P.bias) {
-        const f32x4 b = *(const f32x4*)(P.bias + n);
-        v += b;
+      float v[8] = {lo[0] + b0[0], lo[1] + b0[1], lo[2] + b0[2], lo[3] + b0[3],
+                    hi[0] + b1[0], hi[1] + b1[1], hi[2] + b1[2], hi[3] + b1[3]};
+      const int mo = out_row(m);
+      if (HAS_PREF32 && epre) {
+        float* dst = eCf + (unsigned)(mo * eldcf + n);
+        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
       }
-      if (P.pre_f32) *(f32x4*)(P.Cf + (size_t)mo * P.ldcf + n) = v;
-      if (P.C2) {
-        bf16x4 o;
+      if (HAS_C2 && eC2) {
+        bf16x8 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r]);
-        *(bf16x4*)(P.C2 + (size_t)mo * P.ldc2 + n) = o;
+        for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
+        *(bf16x8*)(eC2 + (unsigned)(mo * eldc2 + n)) = o;
       }
-      if (act == VG_ACT_MUL_GELU_GRAD) {
-        const bf16x4 z = *(const bf16x4*)(P.Z + (size_t)m * P.ldz + n);
+      if (NEED_ZBF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= vg_gelu_grad(vg_bf2f(z[r]));
-      } else if (act == VG_ACT_MUL_TANH_GRAD) {
-        const bf16x4 z = *(const bf16x4*)(P.Z + (size_t)m * P.ldz + n);
+        for (int r = 0; r < 8; ++r) {
+          const float zv = vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
+          v[r] *= (ACT == VG_ACT_MUL_GELU_GRAD) ? vg_gelu_grad(zv) : (1.f - zv * zv);
+        }
+      } else if (NEED_ZF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float tv = vg_bf2f(z[r]); v[r] *= 1.f - tv * tv; }
-      } else if (act == VG_ACT_MUL_COS) {
-        const f32x4 z = *(const f32x4*)(P.Zf + (size_t)m * P.ldzf + n);
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= ascale * __cosf(ascale * pre_f0[PRE_F ? q : 0][r]);
+          v[r + 4] *= ascale * __cosf(ascale * pre_f1[PRE_F ? q : 0][r]);
+        }
+      } else if (ACT != VG_ACT_NONE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= ascale * __cosf(ascale * z[r]);
-      } else if (act != VG_ACT_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(act, ascale, v[r]);
+        for (int r = 0; r < 8; ++r) v[r] = apply_act<ACT>(ascale, v[r]);
       }
-      if (P.res) {
-        const bf16x4 rr = *(const bf16x4*)(P.res + (size_t)mo * P.ldr + n);
+      if (HAS_RES && !NEED_ZBF && eres) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += vg_bf2f(rr[r]);
+        for (int r = 0; r < 8; ++r) v[r] += vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
       }
-      if (P.resf) {
-        const f32x4 rr = *(const f32x4*)(P.resf + (size_t)(m % P.res_period) * P.N + n);
-        v += rr;
-      }
-      if (P.C) {
-        bf16x4 o;
+      if (HAS_RESF && !NEED_ZF && eresf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r]);
-        *(bf16x4*)(P.C + (size_t)mo * P.ldc + n) = o;
+        for (int r = 0; r < 4; ++r) { v[r] += pre_f0[PRE_F ? q : 0][r]; v[r + 4] += pre_f1[PRE_F ? q : 0][r]; }
+      }
+      if (eC) {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
+        *(bf16x8*)(eC + (unsigned)(mo * eldc + n)) = o;
       }
     }
   }
+#ifdef VG_STAMPS
+  STAMP(7);
+  if (tid == 0 && grp.stamps) {
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = grp.stamps + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
+  }
+#endif
 }
+
+__device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 0u, 0u};
 
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return -1;
+  // tile height: 256 rows (8 waves) when every problem is tall enough to fill the chip that way
+  int wm4 = 1;
+  for (int i = 0; i < n; ++i)
+    if (probs[i].M < 4096 || mode == VG_TN) wm4 = 0;
+  if (const char* e = getenv("VG_GEMM_WM")) wm4 = (atoi(e) == 4) && mode != VG_TN;
+  const int bm = wm4 ? 256 : 128;
+  static const bool dbg_nostore = getenv("VG_GEMM_DEBUG_NOSTORE") != nullptr;  // timing experiments only
   VgGemmGroup grp;
   grp.n = n;
+#ifdef VG_STAMPS
+  grp.stamps = getenv("VG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("VG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
+  {
+    static void* zp = nullptr;  // one device per process (one process per GPU)
+    if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(vg_zero_page)) != hipSuccess) return -5;
+    grp.zeros = zp;
+  }
   int total = 0;
   for (int i = 0; i < n; ++i) {
     VgGemmProb& p = probs[i];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
     // 16-byte vector loads: contiguous extents and leading dims must be multiples of 8 elements
     if ((p.lda & 7) || (p.ldb & 7) || (p.N & 7)) return -3;
+    // epilogue addresses are base + 32-bit element offsets
+    if ((long long)(p.M + 256) * (long long)(p.N > p.ldc ? p.N : p.ldc) >= (1LL << 31)) return -3;
     if (mode == VG_NT && (p.K & 7)) return -3;
     if (mode == VG_NN && (p.K & 7)) return -3;
     if (mode == VG_TN && (p.M & 7)) return -3;
-    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + BN - 1) / BN;
     int splits = (mode == VG_TN) ? (p.splits > 0 ? p.splits : 1) : 1;
     int ksteps = (p.K + BK - 1) / BK;
@@ -260,16 +402,61 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     p.k_per_split = per * BK;
     splits = (ksteps + per - 1) / per;  // drop empty slices
     p.splits = splits;
+    if (dbg_nostore && mode != VG_TN) { p.C = nullptr; p.C2 = nullptr; p.pre_f32 = 0; }
     p.tile_start = total;
     total += p.tiles_m * p.tiles_n * splits;
     grp.p[i] = p;
   }
-  dim3 grid(total), block(256);
-  switch (mode) {
-    case VG_NT: hipLaunchKernelGGL(vg_gemm_kernel<VG_NT>, grid, block, 0, stream, grp); break;
-    case VG_NN: hipLaunchKernelGGL(vg_gemm_kernel<VG_NN>, grid, block, 0, stream, grp); break;
-    case VG_TN: hipLaunchKernelGGL(vg_gemm_kernel<VG_TN>, grid, block, 0, stream, grp); break;
-    default: return -4;
+  dim3 grid(total);
+  const int act = probs[0].act;
+  for (int i = 1; i < n; ++i)
+    if (probs[i].act != act) return -4;  // one epilogue per launch
+#define VG_LAUNCH(MODE_, WM_, ACT_, FEAT_) \
+  hipLaunchKernelGGL((vg_gemm_kernel<MODE_, WM_, ACT_, FEAT_>), grid, dim3(128 * WM_), 0, stream, grp)
+#define VG_BY_WM(MODE_, ACT_, FEAT_) do { if (wm4) VG_LAUNCH(MODE_, 4, ACT_, FEAT_); else VG_LAUNCH(MODE_, 2, ACT_, FEAT_); } while (0)
+  // features any problem of the group needs
+  int feat = 0;
+  for (int i = 0; i < n; ++i) {
+    const VgGemmProb& q = probs[i];
+    if (q.res) feat |= F_RES;
+    if (q.resf) feat |= F_RESF;
+    if (q.row_in_per > 0) feat |= F_REMAP;
+    if (q.C2) feat |= F_C2;
+    if (q.pre_f32) feat |= F_PREF32;
   }
+  if (mode == VG_NT) {
+    if (act == VG_ACT_NONE) {
+      if (feat == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, 0);
+      else if (feat == F_RES) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RES);
+      else if ((feat & ~(F_RESF | F_REMAP)) == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RESF | F_REMAP);
+      else VG_BY_WM(VG_NT, VG_ACT_NONE, F_ALL);
+    } else if (act == VG_ACT_GELU) {
+      if ((feat & ~F_C2) == 0) VG_BY_WM(VG_NT, VG_ACT_GELU, F_C2);
+      else VG_BY_WM(VG_NT, VG_ACT_GELU, F_ALL);
+    } else if (act == VG_ACT_SIN) {
+      if ((feat & ~F_PREF32) == 0) VG_BY_WM(VG_NT, VG_ACT_SIN, F_PREF32);
+      else VG_BY_WM(VG_NT, VG_ACT_SIN, F_ALL);
+    } else if (act == VG_ACT_TANH) {
+      VG_BY_WM(VG_NT, VG_ACT_TANH, F_ALL);
+    } else {
+      return -4;
+    }
+  } else if (mode == VG_NN) {
+    if (feat != 0) return -4;  // dgrad epilogues take no residual / second output
+    switch (act) {
+      case VG_ACT_NONE: VG_BY_WM(VG_NN, VG_ACT_NONE, 0); break;
+      case VG_ACT_MUL_GELU_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_GELU_GRAD, 0); break;
+      case VG_ACT_MUL_COS: VG_BY_WM(VG_NN, VG_ACT_MUL_COS, 0); break;
+      case VG_ACT_MUL_TANH_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_TANH_GRAD, 0); break;
+      default: return -4;
+    }
+  } else if (mode == VG_TN) {
+    if (act != VG_ACT_NONE) return -4;
+    VG_LAUNCH(VG_TN, 2, VG_ACT_NONE, 0);
+  } else {
+    return -4;
+  }
+#undef VG_BY_WM
+#undef VG_LAUNCH
   return (int)hipGetLastError();
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void vg_sln_fwd_kernel(const bf16* __restrict_
 //   part[wg][3E], [3E+1] = SLN scalars d gs, d bs      (SLN only; width 3E+64)
 // dx_out = (gres ? gres : 0) + LN-backward(dy_eff).
 // SLN: dy_eff = dy * w * gs;  dw_acc (+)= dy * (gs*(xhat*lw+lb)+bs)  (fp32 accumulator [R,E]).
-template <bool SLN>
+template <bool SLN, int NPL>
 __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                         int x_bcast_rows, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -121,10 +121,9 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
                                                         int dw_accumulate, int R, int E) {
   __shared__ float red[4 * 64 * LN_MAX_PER_LANE];  // [wave][E]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int npl = E >> 7;
-  float ag[LN_MAX_PER_LANE], ab[LN_MAX_PER_LANE], ac[LN_MAX_PER_LANE];
+  float ag[2 * NPL], ab[2 * NPL], ac[2 * NPL];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
+  for (int i = 0; i < 2 * NPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
   float s_gs = 0.f, s_bs = 0.f;
   const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
   // rows are dealt to (workgroup, wave) pairs round-robin: wave w of block b takes rows
@@ -134,11 +133,11 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
     const bf16x2* xr = (const bf16x2*)(x + (size_t)xrow * E);
     const bf16x2* dr = (const bf16x2*)(dy + (size_t)row * E);
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAX_PER_LANE], gg[LN_MAX_PER_LANE];
+    float xh[2 * NPL], gg[2 * NPL];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-      if (i < npl) {
+    for (int i = 0; i < NPL; ++i)
+      {
         const int c = 2 * (lane + 64 * i);
         const bf16x2 xv = xr[lane + 64 * i];
         const bf16x2 dv = dr[lane + 64 * i];
@@ -167,8 +166,8 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
     c2 = vg_wave_sum(c2) / (float)E;
     bf16x2* oxr = (bf16x2*)(dx + (size_t)row * E);
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-      if (i < npl) {
+    for (int i = 0; i < NPL; ++i)
+      {
         float o0 = rs * (gg[2 * i] - c1 - xh[2 * i] * c2);
         float o1 = rs * (gg[2 * i + 1] - c1 - xh[2 * i + 1] * c2);
         if (gres) {
@@ -187,8 +186,8 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
   for (int which = 0; which < 3; ++which) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-      if (i < npl) {
+    for (int i = 0; i < NPL; ++i)
+      {
         const int c = 2 * (lane + 64 * i);
         const float a0 = which == 0 ? ag[2 * i] : (which == 1 ? ab[2 * i] : ac[2 * i]);
         const float a1 = which == 0 ? ag[2 * i + 1] : (which == 1 ? ab[2 * i + 1] : ac[2 * i + 1]);
@@ -215,16 +214,18 @@ struct VgSeg { float* dst; int n; };
 struct VgSegs { VgSeg s[4]; };
 __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restrict__ part, int rows, int width,
                                                             VgSegs segs, int accumulate) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float a = 0.f;
   if (c < width)
-    for (int r = rl; r < rows; r += 8) a += part[(size_t)r * width + c];
+    for (int r = rl; r < rows; r += 16) a += part[(size_t)r * width + c];
   red[rl][cl] = a;
   __syncthreads();
   if (rl != 0 || c >= width) return;
-  a = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+  a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a += red[k][cl];
   int off = 0; float* dst = nullptr;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -235,19 +236,32 @@ __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restr
   if (accumulate) *dst += a; else *dst = a;
 }
 
-// partial column sums of a bf16 matrix: part[chunk][c] = sum over the chunk's rows of X[r][c]
+// partial column sums of a bf16 matrix: part[chunk][c] = sum over the chunk's rows of X[r][c].
+// One workgroup = 256 columns x CS_ROWS rows: thread (cg, rl) loads 16 B (8 columns) of rows rl, rl+8, ...
+#define CS_ROWS 256
 __global__ __launch_bounds__(256) void vg_colsum_bf16_part_kernel(const bf16* __restrict__ X, long long ld, int R, int N,
-                                                                  int rows_per_chunk, float* __restrict__ part) {
-  const int c = 2 * (blockIdx.x * 256 + threadIdx.x);
-  if (c >= N) return;
-  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
-  float a0 = 0.f, a1 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const bf16x2 t = *(const bf16x2*)(X + (size_t)r * ld + c);
-    a0 += vg_bf2f(t[0]); a1 += vg_bf2f(t[1]);
+                                                                  float* __restrict__ part) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + cg * 8;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const bf16x8 t = *(const bf16x8*)(X + (size_t)r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += vg_bf2f(t[j]);
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = a[j];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    part[(size_t)blockIdx.y * N + cc] = t;
   }
-  part[(size_t)blockIdx.y * N + c] = a0;
-  part[(size_t)blockIdx.y * N + c + 1] = a1;
 }
 
 // ---------------------------------- host launchers ----------------------------------------
@@ -269,9 +283,15 @@ int vg_ln_bwd_nparts(int R) { const int n = (R + 7) / 8; return n < LN_MAX_PARTS
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, hipStream_t st) {
   if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-  hipLaunchKernelGGL(vg_ln_bwd_kernel<false>, dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma,
-                     (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (float*)nullptr, 0, R, E);
+#define LN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
+                     (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
+                     (const float*)nullptr, (float*)nullptr, 0, R, E)
+  switch (E >> 7) {
+    case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
+    case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; case 8: LN_BWD(8); break;
+    default: return -3;
+  }
+#undef LN_BWD
   return (int)hipGetLastError();
 }
 int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
@@ -279,26 +299,29 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
                       hipStream_t st) {
   if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-  hipLaunchKernelGGL(vg_ln_bwd_kernel<true>, dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean,
-                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, E);
+#define SLN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
+                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, E)
+  switch (E >> 7) {
+    case 1: SLN_BWD(1); break; case 2: SLN_BWD(2); break; case 3: SLN_BWD(3); break; case 4: SLN_BWD(4); break;
+    case 5: SLN_BWD(5); break; case 6: SLN_BWD(6); break; case 7: SLN_BWD(7); break; case 8: SLN_BWD(8); break;
+    default: return -3;
+  }
+#undef SLN_BWD
   return (int)hipGetLastError();
 }
 int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
                          float* d3, int n3, int accumulate, hipStream_t st) {
   VgSegs s; s.s[0] = {d0, n0}; s.s[1] = {d1, n1}; s.s[2] = {d2, n2}; s.s[3] = {d3, n3};
-  hipLaunchKernelGGL(vg_colsum_f32_kernel, dim3((width + 31) / 32), dim3(256), 0, st, part, rows, width, s, accumulate);
+  hipLaunchKernelGGL(vg_colsum_f32_kernel, dim3((width + 15) / 16), dim3(256), 0, st, part, rows, width, s, accumulate);
   return (int)hipGetLastError();
 }
-#define COLSUM_MAX_CHUNKS 128
-static inline int colsum_rows(int R) { int r = (R + COLSUM_MAX_CHUNKS - 1) / COLSUM_MAX_CHUNKS; return r < 32 ? 32 : r; }
-int vg_colsum_bf16_nparts(int R) { const int r = colsum_rows(R); return (R + r - 1) / r; }
+int vg_colsum_bf16_nparts(int R) { return (R + CS_ROWS - 1) / CS_ROWS; }
 // dst[c] (+)= sum_r X[r][c]; `part` needs vg_colsum_bf16_nparts(R) * N floats of scratch.
 int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
                           hipStream_t st) {
-  if ((N & 1) || R < 1) return -3;
+  if ((N & 7) || (ld & 7) || R < 1) return -3;
   const int chunks = vg_colsum_bf16_nparts(R);
-  hipLaunchKernelGGL(vg_colsum_bf16_part_kernel, dim3((N / 2 + 255) / 256, chunks), dim3(256), 0, st, X, ld, R, N,
-                     colsum_rows(R), part);
+  hipLaunchKernelGGL(vg_colsum_bf16_part_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, st, X, ld, R, N, part);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   return vg_colsum_f32_launch(part, chunks, N, dst, N, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, st);

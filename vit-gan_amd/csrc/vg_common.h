@@ -48,13 +48,28 @@ __device__ __forceinline__ float vg_wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float vg_gelu(float x) {  // exact erf form (nn.GELU default)
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below one bf16 ulp): one v_exp, one v_rcp,
+// a 5-term Horner chain - ~12 instructions instead of libm's branchy erff (keeps GEMM epilogues small).
+__device__ __forceinline__ float vg_erf_pos(float ax, float e /* = exp(-ax*ax) */) {
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 1.0f - poly * e;
 }
-__device__ __forceinline__ float vg_gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+__device__ __forceinline__ float vg_gelu(float x) {  // exact-erf GELU (nn.GELU default) to ~1e-7
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-ax * ax);
+  const float er = copysignf(vg_erf_pos(ax, e), x);
+  return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float vg_gelu_grad(float x) {  // Phi(x) + x * phi(x); exp(-x^2/2) shared by both terms
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-ax * ax);
+  const float er = copysignf(vg_erf_pos(ax, e), x);
+  return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float vg_tanh(float x) {  // 1 - 2/(exp(2x)+1), saturates cleanly for |x| large
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
 
 // Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless, so the

@@ -42,6 +42,10 @@ struct VgGemmProb {
 #define VG_MAX_GROUP 4
 struct VgGemmGroup {
   int n;
+#ifdef VG_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: per-workgroup s_memrealtime stamps
+#endif
+  const void* zeros;  // 16 zero bytes in device memory: source of out-of-range LDS-DMA lanes
   VgGemmProb p[VG_MAX_GROUP];
 };
 
