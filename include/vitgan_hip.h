@@ -139,6 +139,13 @@ int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16,
  * (G += dL/dP); 0 skips every weight-gradient kernel (generator pass through D, training.py:204-210). */
 int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img,
                     int want_wgrad, void* stream);
+/* The same backward in pieces, for overlapping the data-parallel gradient all-reduce with compute:
+ * stage 0 = classifier head + final LayerNorm, stages 1..L = encoder blocks L-1..0, stage L+1 = patch
+ * embedding.  Calls must cover [0, L+2) in increasing order on one stream with the same arguments.
+ * After a call returning stages up to s, the gradients of blocks >= L-s (a contiguous tail of the
+ * flat buffer, from layer0 + (L-s)*layer_stride) are final for this backward. */
+int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img,
+                           int want_wgrad, int stage_begin, int stage_end, void* stream);
 
 /* v1 generator: mapping Linear -> L x TransformerSLN -> SLN -> SIREN x2 (src/v1/generator.py:58-69). */
 typedef struct VgGenDims {

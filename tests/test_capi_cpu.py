@@ -1,0 +1,125 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports everything include/vitgan_hip.h
+declares, layouts are consistent, and the nn.Module surface matches the reference's contract."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vit_gan_amd  # noqa: F401
+from vit_gan_amd import _lib, flat
+from vit_gan_amd.config import Config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "vitgan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vitgan_hip.h but not exported"
+        assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert set(_lib._SIGNATURES) <= set(names), set(_lib._SIGNATURES) - set(names)
+    assert lib.vg_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device (negative codes)."""
+    lib = _lib.lib()
+    assert lib.vg_attention_fwd(None, None, None, 1, 1, 1, 32, 1.0, None) == -1
+    assert lib.vg_linear_fwd(None, None, None, None, None, None, None, 8, 8, 8, 0, 0.0, None) == -1
+    d = _lib.VgVitDims(3, 32, 4, 100, 4, 6, 2, 1)  # E not a multiple of 128
+    assert lib.vg_vit_layout(C.byref(d), C.byref(_lib.VgVitLayout())) == -3
+    assert lib.vg_vit_ws_bytes(C.byref(d), 4) == -1
+    d = _lib.VgVitDims(3, 64, 4, 384, 4, 6, 2, 1)  # 257 tokens > 80
+    assert lib.vg_vit_layout(C.byref(d), C.byref(_lib.VgVitLayout())) == -3
+
+
+@pytest.mark.parametrize("dims", [(3, 32, 4, 384, 4, 6, 2, 1), (3, 32, 4, 128, 4, 6, 2, 10), (3, 64, 8, 512, 8, 6, 2, 1),
+                                  (3, 128, 16, 768, 12, 6, 2, 1)])
+def test_vit_layout_is_a_partition(dims):
+    d = _lib.VgVitDims(*dims)
+    lay = flat.vit_layout(d)
+    slots = flat.vit_slots(d)
+    iv = sorted((o, o + flat.numel(s)) for o, s in slots.values())
+    assert iv[0][0] >= 0 and iv[-1][1] <= lay.total
+    assert all(a[1] <= b[0] for a, b in zip(iv, iv[1:])), "overlapping parameter slots"
+    assert all(o % 8 == 0 for o, _ in slots.values() if True), "16-byte alignment of every bf16 slot"
+    # q|k|v weights and biases are adjacent (one fused [3E,E] GEMM operand)
+    E = d.E
+    q, k, v = (slots[f"vit.encoder.0.attention.{n}.weight"][0] for n in ("queries", "keys", "values"))
+    assert k == q + E * E and v == k + E * E
+    assert lay.total % 4 == 0 and lib_ws(d) > 0
+
+
+def lib_ws(d):
+    return _lib.lib().vg_vit_ws_bytes(C.byref(d), 8)
+
+
+def test_config_is_the_references():
+    c = Config()
+    assert list(Config.model_fields) == ["attention_heads_count", "batch_size", "classes_count", "discriminator_learning_rate",
+                                         "dropout_rate", "embeddings_dimension", "epochs", "generator_learning_rate", "image_size",
+                                         "input_channels", "mlp_ratio", "optimizer_beta1", "optimizer_beta2", "patch_size",
+                                         "transformer_blocks_count"]
+    assert (c.embeddings_dimension, c.batch_size, c.classes_count, c.dropout_rate, c.epochs) == (128, 64, 10, 0.1, 500)
+    assert str(c).splitlines()[0] == "attention_heads_count=4" and len(str(c).splitlines()) == 15
+
+
+def test_module_state_dict_contract_and_flat_storage():
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator, ViTGAN, ViTGenerator
+    npz = np.load(os.path.join(GOLD, "vit_c1.npz"))
+    D = ViTDiscriminator(Config(embeddings_dimension=384, classes_count=1))
+    sd = D.state_dict()
+    assert list(sd.keys()) == [str(s) for s in npz["param_names"]]  # the reference module's own key list
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in npz["param_shapes"]]
+    fp = D.vit._flat
+    assert fp.aliased()
+    # parameters are views of the flat buffer; load_state_dict writes through
+    new = {k: torch.full_like(v, 0.25) for k, v in sd.items()}
+    D.load_state_dict(new, strict=True)
+    assert float(fp.flat.sum()) == pytest.approx(0.25 * sum(v.numel() for v in sd.values()))
+    # grads are views of one buffer, zero_grad keeps them attached
+    D.zero_grad()
+    base = fp.grad.data_ptr()
+    assert all(p.grad is not None and base <= p.grad.data_ptr() < base + 4 * fp.total for p in D.parameters())
+    g = np.load(os.path.join(GOLD, "gen_g1.npz"))
+    G = SirenGenerator()
+    assert list(G.state_dict().keys()) == [str(s) for s in g["param_names"]]
+    assert [str(tuple(v.shape)) for v in G.state_dict().values()] == [str(s) for s in g["param_shapes"]]
+    v2 = np.load(os.path.join(GOLD, "vitgen_v2.npz"))
+    assert list(ViTGenerator(Config(classes_count=10, batch_size=3, embeddings_dimension=384, transformer_blocks_count=2)).state_dict().keys()) == \
+        [str(s) for s in v2["illegal/state_keys"]]
+    assert len(ViTGAN(Config()).state_dict()) == 214
+
+
+def test_no_cpu_fallback():
+    from vit_gan_amd import ops
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator
+    D = ViTDiscriminator(Config())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SirenGenerator(layers=1)(torch.zeros(2, 1024))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(8, 8))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vit-gan_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), f"{fn} mentions the oracle"

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks.  (a) GradSync range all-reduce; (b) sharding the batch over ranks and
+averaging the summed gradients reproduces the single-process gradient of the global batch (the data-parallel
+contract of SURVEY 8e), checked with the fp32 oracle as the per-rank compute."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import vit_gan_amd  # noqa: F401
+        from vit_gan_amd.dist import GradSync, shard_batch
+        from oracle import step_oracle as so, vit_oracle as vo
+
+        torch.set_num_threads(2)
+        sync = GradSync(None, torch.device("cpu"))
+        assert sync.world == world and not sync.overlap
+        # (a) ranges
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        sync.reduce_range(flat, 100, 900)
+        sync.wait()
+        ref = torch.arange(1000, dtype=torch.float32)
+        tot = sum(r + 1 for r in range(world))
+        assert torch.equal(flat[100:900], ref[100:900] * tot) and torch.equal(flat[:100], ref[:100] * (rank + 1))
+        # (b) sharded D gradient == global-batch gradient
+        d = vo.VitDims(embed=128, heads=4, layers=1, classes=1)
+        st = {k: v.clone().requires_grad_(True) for k, v in vo.init_vit_state(d, 7).items()}
+        GB = 8
+        g = torch.Generator().manual_seed(3)
+        real = torch.rand(GB, 3, 32, 32, generator=g) * 2 - 1
+        lo, hi = shard_batch(GB, rank, world)
+        so.d_loss_real(vo.vit_forward(st, real[lo:hi], d), "ns").backward()
+        names = list(st)
+        flat_g = torch.cat([st[k].grad.reshape(-1) for k in names])
+        sync.reduce_range(flat_g, 0, flat_g.numel())
+        sync.wait()
+        flat_g /= world  # the 1/world factor the fused AdamW applies as `gscale`
+        if rank == 0:
+            st2 = {k: v.detach().clone().requires_grad_(True) for k, v in st.items()}
+            so.d_loss_real(vo.vit_forward(st2, real, d), "ns").backward()
+            ref_g = torch.cat([st2[k].grad.reshape(-1) for k in names])
+            err = float((flat_g - ref_g).abs().max()) / float(ref_g.abs().max())
+            out.put(("ok", err))
+    except Exception as e:  # surface the failure in the parent
+        out.put(("err", f"rank {rank}: {type(e).__name__}: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_gradient_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, val = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == "ok", val
+    assert val < 1e-5, f"sharded gradient differs from the global-batch gradient: rel err {val}"
+
+
+def test_shard_batch():
+    from vit_gan_amd.dist import shard_batch
+    assert [shard_batch(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)

@@ -41,8 +41,10 @@ def test_engine_step_matches_oracle(loss, fuse):
         z = eng.z.detach().cpu().clone()  # the noise the engine drew
         ref = oracle.step(real, z)
         got = losses.cpu().tolist()
-        # bf16 forward of a freshly initialised net: logits ~1e-2, losses ~0.69 / ~1.0
-        assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)
+        # step 0: same weights, bf16 vs fp32 forward -> |dloss| < 2e-2.  step 1: each net has taken one
+        # AdamW step whose per-weight direction is sign(g) (noise-level gradients may flip) -> 4e-2.
+        tol = 2e-2 if it == 0 else 4e-2
+        assert abs(got[0] - ref["d_real"]) < tol and abs(got[1] - ref["d_fake"]) < tol and abs(got[2] - ref["g"]) < tol, (got, ref)
     # after two AdamW steps the weights must track the oracle: AdamW moves each weight by ~lr per
     # step whatever the gradient scale, so compare the UPDATE direction on well-conditioned tensors
     sd = {k: v.detach().cpu() for k, v in D.state_dict().items()}

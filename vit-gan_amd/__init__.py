@@ -7,3 +7,4 @@ hand-written HIP kernels through a C ABI (include/vitgan_hip.h).  Import as
 from . import _lib  # noqa: F401
 
 __all__ = ["_lib"]
+from .config import Config  # noqa: E402,F401

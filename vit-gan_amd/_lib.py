@@ -69,6 +69,7 @@ _SIGNATURES = {
     "vg_vit_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
     "vg_vit_forward": (c_int, [C.POINTER(VgVitNet), c_int, P, c_int, P, P, P]),
     "vg_vit_backward": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, P]),
+    "vg_vit_backward_stages": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, c_int, c_int, P]),
     "vg_gen_layout": (c_int, [C.POINTER(VgGenDims), C.POINTER(VgGenLayout)]),
     "vg_gen_ws_bytes": (c_ll, [C.POINTER(VgGenDims), c_int]),
     "vg_gen_forward": (c_int, [C.POINTER(VgGenNet), c_int, P, P, P, P]),

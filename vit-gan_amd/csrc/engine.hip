@@ -246,9 +246,13 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   return 0;
 }
 
-extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
-                               void* stream) {
+// Backward stages: 0 = classifier head + final LN, 1..L = encoder blocks L-1 .. 0, L+1 = patch embedding.
+// Running [stage_begin, stage_end) lets the caller all-reduce the gradients of finished blocks (a contiguous
+// range of the flat buffer) on another stream while the remaining stages still compute.
+extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
+                                      int stage_begin, int stage_end, void* stream) {
   if (!net || !ws || !dlogits || B < 1) return -1;
+  if (stage_begin < 0 || stage_end > net->d.L + 2 || stage_begin >= stage_end) return -2;
   if (want_wgrad && !net->G) return -1;
   const VgVitDims& d = net->d;
   VgVitLayout lay;
@@ -261,6 +265,11 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
   const size_t ME = (size_t)M * E;
   const int lnparts = vg_ln_bwd_nparts(M);
 
+  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
+  const int layers_done = stage_begin > 0 ? stage_begin - 1 : 0;  // blocks already processed by earlier calls
+  if (layers_done & 1) { bf16* t = g; g = gin; gin = t; }          // g and gin swap once per block
+  bool have_g_colsum = layers_done > 0;  // part[:, 2E:3E] holds colsum(g) when g came out of an LN backward
+  if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
   VG_TRY(vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr,
                             want_wgrad ? G + lay.hb2 : nullptr, B, E, d.Kc, want_wgrad, st));
@@ -274,11 +283,13 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
   VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, st));
   if (want_wgrad)
     VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
-  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   VG_TRY(vg_scatter_cls_launch(w.dxcls, g, B, S, E, st));
-  bool have_g_colsum = false;  // part[:, 2E:3E] holds colsum(g) when g came out of an LN backward
+  }
 
   for (int l = d.L - 1; l >= 0; --l) {
+    const int stage = d.L - l;
+    if (stage < stage_begin) continue;
+    if (stage >= stage_end) break;
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* x = w.X + (size_t)l * ME;
     const bf16* xn1 = w.xn1 + (size_t)l * ME;
@@ -322,6 +333,7 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
     bf16* t = g; g = gin; gin = t;  // g now = dL/dX[l]
   }
 
+  if (stage_end < d.L + 2) return 0;
   // ---- patch embedding ----
   if (want_wgrad) {
     VG_TRY(vg_batch_sum_launch(g, w.tok_sum, B, S, E, st));
@@ -339,6 +351,12 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
     VG_TRY(vg_unpatchify_launch(w.dA, (bf16*)d_img, B, d.C, d.IH, d.P, st));
   }
   return 0;
+}
+
+extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
+                               void* stream) {
+  if (!net) return -1;
+  return vg_vit_backward_stages(net, B, ws, dlogits, d_img, want_wgrad, 0, net->d.L + 2, stream);
 }
 
 // =============================================================================================

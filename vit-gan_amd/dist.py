@@ -1,0 +1,62 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The G/D step shards by samples (every loss is a mean over independent samples and the ViT path has
+no BatchNorm - SURVEY 8e), so the only exchange is a SUM all-reduce of each network's flat fp32
+gradient buffer once per optimizer step; the 1/world factor is folded into the fused AdamW kernel.
+``GradSync`` launches the all-reduce of a finished range of the flat buffer on a side stream while the
+backward of the remaining blocks is still running (xGMI is point-to-point: few, large messages).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def shard_batch(global_batch: int, rank: int, world: int):
+    """[begin, end) of this rank's samples; the global batch must divide evenly (weak scaling keeps the
+    per-GPU batch fixed, so bench.py never hits the remainder case)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class GradSync:
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
+                 overlap: bool = True):
+        self.group = group
+        self.world = world_size(group)
+        self.cuda = device is not None and device.type == "cuda"
+        self.overlap = bool(overlap) and self.cuda and self.world > 1
+        self.comm = torch.cuda.Stream(device=device) if self.overlap else None
+        self._pending: List = []
+
+    def reduce_range(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """SUM all-reduce flat[lo:hi] across ranks.  With overlap the collective runs on the side stream
+        after everything already enqueued on the current stream (which produced those gradients)."""
+        if self.world == 1 or hi <= lo:
+            return
+        view = flat[lo:hi]
+        if not self.overlap:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self) -> None:
+        """Make the current stream wait for every all-reduce launched since the last wait()."""
+        if not self.overlap:
+            return
+        for w in self._pending:
+            w.wait()  # current stream waits for the collective
+        self._pending.clear()
+        torch.cuda.current_stream().wait_stream(self.comm)

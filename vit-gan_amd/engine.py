@@ -21,7 +21,8 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, flat
+from .dist import GradSync
 from .generator import SirenGenerator
 from .modules import ViTDiscriminator, VisionTransformer
 
@@ -50,7 +51,8 @@ class GanEngine:
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.sync = GradSync(process_group, self.dev, overlap=True)
+        self.world = self.sync.world
         d, g = vit._dims, generator._dims
         if g.T * g.CW != d.C * d.IH * d.IH:
             raise ValueError("generator output does not match the discriminator's image shape")
@@ -84,9 +86,22 @@ class GanEngine:
         ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr())
         return nd, ng
 
-    def _allreduce(self, flat_grad: torch.Tensor) -> None:
-        if self.world > 1:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+    def _d_backward(self, nd, n_img: int, dl, want_w: int, dimg, st) -> None:
+        """D backward; under data parallelism in two halves so that the all-reduce of the upper blocks'
+        gradients (a contiguous tail of the flat buffer) overlaps the backward of the lower blocks."""
+        L = _lib.lib()
+        nL = self.vit._dims.L
+        if self.world == 1 or not want_w:
+            _lib.check(L.vg_vit_backward(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, st), "vg_vit_backward")
+            return
+        fd = self.vit._flat
+        lay = flat.vit_layout(self.vit._dims)
+        half = nL // 2
+        cut = lay.layer0 + (nL - half) * lay.layer_stride  # blocks >= nL-half and the head are final after part 1
+        _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, 0, 1 + half, st), "vg_vit_backward_stages")
+        self.sync.reduce_range(fd.grad, cut, fd.total)
+        _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, 1 + half, nL + 2, st), "vg_vit_backward_stages")
+        self.sync.reduce_range(fd.grad, 0, cut)
 
     def _adamw(self, fp, m, v, lr, st):
         h = self.hyp
@@ -116,7 +131,7 @@ class GanEngine:
             _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(self.imgs), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
             self._loss(0, B, 0, 0, st)
             self._loss(B, B, 1, 1, st)
-            _lib.check(L.vg_vit_backward(C.byref(nd), 2 * B, _p(self.ws_d), _p(self.dlogits), None, 1, st), "vg_vit_backward")
+            self._d_backward(nd, 2 * B, _p(self.dlogits), 1, None, st)
         else:
             for half, role in ((0, 0), (1, 1)):
                 src = C.c_void_p(self.imgs.data_ptr() + half * B * img_bytes)
@@ -124,15 +139,19 @@ class GanEngine:
                 dl = C.c_void_p(self.dlogits.data_ptr() + 4 * half * B * self.Kc)
                 _lib.check(L.vg_vit_forward(C.byref(nd), B, src, 1, _p(self.ws_d), lg, st), "vg_vit_forward")
                 self._loss(half * B, B, role, role, st)
-                _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), dl, None, 1, st), "vg_vit_backward")
-        self._allreduce(fd.grad)
+                if half == 0:
+                    _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), dl, None, 1, st), "vg_vit_backward")
+                else:  # second pass finishes D.grad: exchange it as it completes
+                    self._d_backward(nd, B, dl, 1, None, st)
+        self.sync.wait()
         self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st)
         fg.grad.zero_()            # gan.generator.zero_grad(), training.py:199
         _lib.check(L.vg_vit_forward(C.byref(nd), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
         self._loss(0, B, 2, 2, st)
         _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st), "vg_vit_backward")
         _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
-        self._allreduce(fg.grad)
+        self.sync.reduce_range(fg.grad, 0, fg.total)
+        self.sync.wait()
         self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st)
 
     def step(self, real: torch.Tensor) -> torch.Tensor:
