@@ -18,10 +18,12 @@ torch.cuda.synchronize()
 t=st.cpu().numpy().reshape(nwg,8).astype(np.float64)
 t0=t[:,0].min()
 rel=(t[:,:8]-t0)/100.0  # us (100 MHz)
-print("nwg",nwg,"kernel span us",rel[:,7].max())
+print("K",K,"dbg",os.environ.get("VG_GEMM_DBG","0"),"WM",os.environ.get("VG_GEMM_WM","4"),"nwg",nwg,"kernel span us",round(rel[:,7].max(),1), "mainloop per-step us", round(float(np.median(d[:,3]))/(K/32),3)) if False else None
 d=np.diff(t[:,:8],axis=1)/100.0
+print('K',K,'dbg',os.environ.get('VG_GEMM_DBG','0'),'WM',os.environ.get('VG_GEMM_WM','4'),'nwg',nwg,'span us',round(float(rel[:,7].max()),1),'mainloop/step us',round(float(np.median(d[:,3]))/(K/32),3),'epilogue us',round(float(np.median(d[:,4]+d[:,5]+d[:,6])),2))
 names=["setup","issue3","first-wait","mainloop","ep-barrier","ep-prefetch","ep-body"]
-for i,n in enumerate(names): print(f"{n:10s} mean {d[:,i].mean():7.2f} us  p50 {np.median(d[:,i]):7.2f}  max {d[:,i].max():7.2f}")
-print("wg lifetime mean", (t[:,7]-t[:,0]).mean()/100.0)
+for i,n in enumerate(names):
+    if os.environ.get("VERBOSE"): print(f"{n:10s} mean {d[:,i].mean():7.2f} us  p50 {np.median(d[:,i]):7.2f}  max {d[:,i].max():7.2f}")
+if os.environ.get("VERBOSE"): print("wg lifetime mean", (t[:,7]-t[:,0]).mean()/100.0)
 order=np.argsort(t[:,0]); 
-print("start times (us) of WGs by order: ", [round(float(rel[order[i],0]),2) for i in (0,100,255,256,511,512,700,1000,nwg-1) if i<nwg])
+if os.environ.get("VERBOSE"): print("start times (us) of WGs by order: ", [round(float(rel[order[i],0]),2) for i in (0,100,255,256,511,512,700,1000,nwg-1) if i<nwg])

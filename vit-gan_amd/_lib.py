@@ -10,7 +10,7 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitgan_hip.so")
+LIB_PATH = os.environ.get("VITGAN_HIP_LIB", os.path.join(_HERE, "libvitgan_hip.so"))  # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong

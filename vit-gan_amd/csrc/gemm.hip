@@ -23,7 +23,14 @@
 #define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
 #define BK 32
-#define NSTAGE 4            // LDS ring: 3 k-steps in flight behind a counted vmcnt + 1 being read
+#ifndef NSTAGE_WM2
+#define NSTAGE_WM2 2
+#endif
+#define NSTAGE_WM4 3
+#define NSTAGE (WM == 2 ? NSTAGE_WM2 : NSTAGE_WM4)   // LDS ring: NSTAGE-1 k-steps in flight + 1 being read
+#ifndef OCC_WM2
+#define OCC_WM2 4
+#endif
 #define A_TILE_BYTES (BM * BK * 2)
 #define B_TILE_BYTES 8192
 #define STAGE_BYTES (A_TILE_BYTES + B_TILE_BYTES)
@@ -115,12 +122,16 @@ __device__ __forceinline__ float apply_act(float scale, float v) {
 // smallest compiled superset so the common epilogues carry no dead address arithmetic.
 enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31 };
 
+// Occupancy is the lever on MI355X for these short-K GEMMs (measured: 16 waves/CU beats a deeper DMA ring at
+// 8-12 waves/CU by 25-40 %): WM=2 -> 2-stage ring (32 KiB) x 4 workgroups/CU, WM=4 -> 3-stage ring (72 KiB) x 2
+// workgroups/CU; both 4 waves/SIMD, so at most 128 registers per lane.
 template <int MODE, int WM, int ACT, int FEAT>
-__global__ __launch_bounds__(128 * WM) void vg_gemm_kernel(const VgGemmGroup grp) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_kernel(const VgGemmGroup grp) {
   constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE_BYTES];
+  constexpr int SMEM_BYTES = (NSTAGE * STAGE_BYTES > NW * 32 * 272) ? NSTAGE * STAGE_BYTES : NW * 32 * 272;  // ring, reused by the epilogue
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   // XCD-aware block order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
   // run of tiles so the n-tiles of one m-panel hit the same L2 (bijective for any grid size).
@@ -201,25 +212,46 @@ __global__ __launch_bounds__(128 * WM) void vg_gemm_kernel(const VgGemmGroup grp
   STAMP(2);
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
-    const int ahead = nsteps - 1 - s;  // stages issued after s
-    if (ahead >= 2) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); }
-    else if (ahead == 1) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
+    const int ahead = nsteps - 1 - s;  // stages issued after s (at most NSTAGE-2 of them are in flight here)
+    if (NSTAGE >= 4 && ahead >= 2) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); }
+    else if (NSTAGE >= 3 && ahead >= 1) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef VG_STAMPS
     if (s == 0) STAMP(3);
 #endif
+#ifdef VG_STAMPS
+    const int dbg = grp.dbg;
+    if (s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
+#else
     if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1);
+#endif
     const unsigned char* cur = smem + (s % NSTAGE) * STAGE_BYTES;
     bf16x8 fm[4], fn[4];
+#ifdef VG_STAMPS
+    if (dbg & 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane);
-      fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane);
+      for (int i = 0; i < 4; ++i) { for (int j = 0; j < 8; ++j) { fm[i][j] = (bf16)(float)(s + i); fn[i][j] = (bf16)(float)(lane + i); } }
+    } else
+#endif
+    {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane);
+        fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane);
+      }
     }
+#ifdef VG_STAMPS
+    if (dbg & 4) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)fm[i][0]; acc[0][i][1] += (float)fn[i][1]; }
+    } else
+#endif
+    {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
+    }
   }
 #undef ISSUE
 
@@ -367,9 +399,11 @@ __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return -1;
   // tile height: 256 rows (8 waves) when every problem is tall enough to fill the chip that way
+  // 256-row tiles (8 waves) for tall problems with a light epilogue; transcendental epilogues (GELU, gelu',
+  // sin, cos) run better on 128-row tiles, where more co-resident workgroups overlap that VALU work.
   int wm4 = 1;
   for (int i = 0; i < n; ++i)
-    if (probs[i].M < 4096 || mode == VG_TN) wm4 = 0;
+    if (probs[i].M < 4096 || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
   if (const char* e = getenv("VG_GEMM_WM")) wm4 = (atoi(e) == 4) && mode != VG_TN;
   const int bm = wm4 ? 256 : 128;
   static const bool dbg_nostore = getenv("VG_GEMM_DEBUG_NOSTORE") != nullptr;  // timing experiments only
@@ -377,6 +411,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   grp.n = n;
 #ifdef VG_STAMPS
   grp.stamps = getenv("VG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("VG_STAMP_PTR"), nullptr, 0) : nullptr;
+  grp.dbg = getenv("VG_GEMM_DBG") ? atoi(getenv("VG_GEMM_DBG")) : 0;
 #endif
   {
     static void* zp = nullptr;  // one device per process (one process per GPU)
