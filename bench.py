@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--loss", default="ns", choices=["ns", "hinge"])
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph; -1: auto (single GPU only)")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
+    ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,11 +116,11 @@ def main():
     B = args.batch
     torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
     cfg = Config(embeddings_dimension=384, attention_heads_count=4, transformer_blocks_count=6, mlp_ratio=2, patch_size=4,
-                 image_size=32, input_channels=3, classes_count=1, dropout_rate=0.0, batch_size=B)
-    D = ViTDiscriminator(cfg).to(dev)
-    G = SirenGenerator().to(dev)
+                 image_size=32, input_channels=3, classes_count=1, dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
+    D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
+    G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
     use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
-    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph)
+    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
@@ -164,7 +165,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
                                    "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
-                       "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": 0.0,
+                       "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
                        "parallelism": f"dp{world}", "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
             "roofline": roof,

@@ -82,6 +82,13 @@ int vg_colsum_bf16_parts(int R);
 int vg_colsum_bf16(const void* X, long long ld, int R, int N, float* part_ws, float* dst, int accumulate,
                    void* stream);
 
+/* y = x * mask / keep for dropout site `site` of a network run with (p, seed): exactly the mask the fused
+ * passes apply (element index = position in the row-major tensor; n % 4 == 0).  D sites: 0 embedding,
+ * 1+2l attention branch, 2+2l MLP branch of block l; G sites: 100+2l, 101+2l.  Used by tests and by the
+ * backward where no producer kernel can fuse the mask. */
+int vg_dropout_apply(const void* x, void* y, long long n, float p, unsigned long long seed, int site,
+                     const unsigned* step_dev, void* stream);
+
 /* Fused multi-head self-attention (src/v2/modules.py:128-159 after the projections; src/v1/attention.py
  * :43-52,:97-101).  qkv bf16 [B*S, 3*H*HE] (Q | K | V thirds, head-major inside each third);
  * out bf16 [B*S, H*HE]; lse fp32 [B,H,S].  softmax(scale * q.k).  HE in {32,64,96}, S <= 80. */
@@ -130,6 +137,13 @@ typedef struct VgVitNet {
   const float* P;   /* fp32 master parameters */
   const void* Pb;   /* bf16 shadow of P */
   float* G;         /* fp32 gradient accumulator (same layout); may be NULL when want_wgrad == 0 */
+  /* nn.Dropout(p) at the reference's three sites (modules.py:80,170,176: embedding, after the attention
+   * output projection, after fc2), fused into the GEMM epilogues.  p = 0 disables it (eval mode).  p is
+   * quantised to 1/256; the mask is a counter-based hash of (dropout_seed, site, element index), so the
+   * backward regenerates it: pass the SAME seed to the backward of a forward. */
+  float dropout_p;
+  unsigned long long dropout_seed;
+  const unsigned* dropout_step; /* optional device counter mixed into the mask key (hipGraph replay); NULL = none */
 } VgVitNet;
 /* img: [B,C,IH,IH] fp32 (img_is_bf16 = 0) or bf16; logits fp32 [B,Kc].  ws keeps everything the
  * backward needs; one ws per in-flight forward. */
@@ -168,6 +182,10 @@ typedef struct VgGenNet {
   const float* P;
   const void* Pb;
   float* G;
+  /* Dropout after msha.output_linear and inside the block MLP (src/v1/config.py:36,39: 0.2 / 0.2). */
+  float dropout_p;
+  unsigned long long dropout_seed;
+  const unsigned* dropout_step;
 } VgGenNet;
 /* z fp32 [B,Z]; img bf16 [B, T*CW] (== [B,C,IH,IW] flat view, generator.py:66-68). */
 int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream);

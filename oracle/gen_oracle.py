@@ -103,13 +103,15 @@ def mhsa(state: Mapping[str, Tensor], base: str, x: Tensor, d: GenDims,
 
 
 def sln_block(state: Mapping[str, Tensor], base: str, h: Tensor, w: Tensor, d: GenDims,
-              taps: Optional[dict] = None) -> Tensor:
-    """TransformerSLN.forward, src/v1/transformer.py:85-88 (``w`` is returned unchanged there)."""
-    htmp = mhsa(state, base + "msha.", sln(state, base + "layer_norm_1.", h, w), d, taps) + h
+              taps: Optional[dict] = None, m_attn: Optional[Tensor] = None, m_mlp: Optional[Tensor] = None) -> Tensor:
+    """TransformerSLN.forward, src/v1/transformer.py:85-88 (``w`` is returned unchanged there).
+    m_attn / m_mlp (test hook): explicit multipliers standing in for attention_dropout / the MLP's Dropout."""
+    a = mhsa(state, base + "msha.", sln(state, base + "layer_norm_1.", h, w), d, taps)
+    htmp = (a if m_attn is None else a * m_attn) + h
     # MLP with layers=[] is a single Linear, no activation (src/v1/muilti_layer_perceptron.py:37-42)
     m = F.linear(sln(state, base + "layer_norm_2.", htmp, w),
                  state[base + "mlp.model.0.0.weight"], state[base + "mlp.model.0.0.bias"])
-    return m + htmp
+    return (m if m_mlp is None else m * m_mlp) + htmp
 
 
 def siren(state: Mapping[str, Tensor], base: str, x: Tensor, omega0: float) -> Tensor:
@@ -117,7 +119,8 @@ def siren(state: Mapping[str, Tensor], base: str, x: Tensor, omega0: float) -> T
     return torch.sin(omega0 * F.linear(x, state[base + "linear.weight"], state[base + "linear.bias"]))
 
 
-def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Optional[dict] = None) -> Tensor:
+def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Optional[dict] = None,
+                masks: Optional[Mapping] = None) -> Tensor:
     """Generator.forward, src/v1/generator.py:58-69."""
     B = z.shape[0]
     w = F.linear(z, state["mapping_mlp.model.0.0.weight"], state["mapping_mlp.model.0.0.bias"])
@@ -127,7 +130,9 @@ def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Option
         taps["w"] = w
         taps["blocks"] = []
     for i in range(d.layers):
-        h = sln_block(state, f"transformer_layers.{i}.", h, w, d, taps if i == 0 else None)
+        ma = masks.get(("attn", i)) if masks is not None else None
+        mm = masks.get(("mlp", i)) if masks is not None else None
+        h = sln_block(state, f"transformer_layers.{i}.", h, w, d, taps if i == 0 else None, ma, mm)
         if taps is not None:
             taps["blocks"].append(h)
     y = sln(state, "sln.", h, w)  # (:65)

@@ -80,8 +80,10 @@ def vit_param_shapes(d: VitDims, prefix: str = "vit.") -> Dict[str, tuple]:
     return out
 
 
-def patch_embed(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.") -> Tensor:
-    """EmbedLayer.forward, src/v2/modules.py:82-100 (dropout omitted: p=0 / eval).
+def patch_embed(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.",
+                masks: Optional[Mapping] = None) -> Tensor:
+    """EmbedLayer.forward, src/v2/modules.py:82-100.  ``masks`` (test hook): explicit dropout multipliers
+    (mask / keep) keyed "embed", ("attn", l), ("mlp", l) standing in for nn.Dropout's RNG (:99,:179,:180).
 
     A stride-P, kernel-P convolution is a per-patch matrix product: cut the image
     into PxP tiles, flatten each tile in (c, py, px) order - the memory order of
@@ -96,7 +98,10 @@ def patch_embed(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str 
     tok = tiles @ w.t() + bias  # [B, N, E]   (:84-92)
     tok = tok + state[prefix + "embedding.pos_embedding"]  # (:93-95)
     cls = state[prefix + "embedding.cls_token"].expand(B, 1, E)  # (:96-98)
-    return torch.cat([cls, tok], dim=1)
+    out = torch.cat([cls, tok], dim=1)
+    if masks is not None and "embed" in masks:
+        out = out * masks["embed"]  # self.dropout(x), :99
+    return out
 
 
 def self_attention(state: Mapping[str, Tensor], x: Tensor, heads: int, base: str,
@@ -119,16 +124,17 @@ def self_attention(state: Mapping[str, Tensor], x: Tensor, heads: int, base: str
 
 
 def encoder_block(state: Mapping[str, Tensor], x: Tensor, heads: int, base: str,
-                  taps: Optional[dict] = None) -> Tensor:
-    """Encoder.forward (pre-LN block), src/v2/modules.py:178-183; dropout p=0."""
+                  taps: Optional[dict] = None, m_attn: Optional[Tensor] = None, m_mlp: Optional[Tensor] = None) -> Tensor:
+    """Encoder.forward (pre-LN block), src/v2/modules.py:178-183; dropout1/dropout2 = the given multipliers."""
     E = x.shape[-1]
     h = F.layer_norm(x, (E,), state[base + "norm1.weight"], state[base + "norm1.bias"], 1e-5)
-    x = x + self_attention(state, h, heads, base + "attention.", taps)
+    a = self_attention(state, h, heads, base + "attention.", taps)
+    x = x + (a if m_attn is None else a * m_attn)
     h = F.layer_norm(x, (E,), state[base + "norm2.weight"], state[base + "norm2.bias"], 1e-5)
     h = F.linear(h, state[base + "fc1.weight"], state[base + "fc1.bias"])
     h = F.gelu(h)  # nn.GELU() default = exact erf form (:174)
     h = F.linear(h, state[base + "fc2.weight"], state[base + "fc2.bias"])
-    return x + h
+    return x + (h if m_mlp is None else h * m_mlp)
 
 
 def classifier_head(state: Mapping[str, Tensor], x: Tensor, prefix: str = "vit.") -> Tensor:
@@ -139,15 +145,17 @@ def classifier_head(state: Mapping[str, Tensor], x: Tensor, prefix: str = "vit."
 
 
 def vit_forward(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.",
-                taps: Optional[dict] = None) -> Tensor:
+                taps: Optional[dict] = None, masks: Optional[Mapping] = None) -> Tensor:
     """VisionTransformer.forward, src/v2/modules.py:232-238 ( == ViTDiscriminator.forward :393-395)."""
-    h = patch_embed(state, x, d, prefix)
+    h = patch_embed(state, x, d, prefix, masks)
     if taps is not None:
         taps["embed"] = h
         taps["blocks"] = []
     for i in range(d.layers):
         blk_taps = {} if (taps is not None and i == 0) else None
-        h = encoder_block(state, h, d.heads, f"{prefix}encoder.{i}.", blk_taps)
+        ma = masks.get(("attn", i)) if masks is not None else None
+        mm = masks.get(("mlp", i)) if masks is not None else None
+        h = encoder_block(state, h, d.heads, f"{prefix}encoder.{i}.", blk_taps, ma, mm)
         if taps is not None:
             taps["blocks"].append(h)
             if blk_taps:

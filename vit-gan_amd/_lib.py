@@ -28,7 +28,8 @@ class VgVitLayout(C.Structure):
 
 
 class VgVitNet(C.Structure):
-    _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p)]
+    _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
+                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p)]
 
 
 class VgGenDims(C.Structure):
@@ -43,7 +44,8 @@ class VgGenLayout(C.Structure):
 
 
 class VgGenNet(C.Structure):
-    _fields_ = [("d", VgGenDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p)]
+    _fields_ = [("d", VgGenDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
+                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p)]
 
 
 P = c_void_p
@@ -60,6 +62,7 @@ _SIGNATURES = {
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
     "vg_colsum_bf16_parts": (c_int, [c_int]),
     "vg_colsum_bf16": (c_int, [P, c_ll, c_int, c_int, P, P, c_int, P]),
+    "vg_dropout_apply": (c_int, [P, P, c_ll, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -1,5 +1,6 @@
-// Fused multi-head self-attention (forward and backward) for short sequences (S <= 80),
-// one wave64 per (image, head).  gfx950 only.
+// Fused multi-head self-attention (forward and backward) for short sequences (S <= 80): one workgroup
+// per (image, head), ONE WAVE PER 16-ROW TILE (5 waves for S = 65) so that a CU holds 15-20 waves -
+// these kernels are latency bound and occupancy is what hides it.  gfx950 only.
 //
 // The whole S x S score tile lives in MFMA accumulators; softmax runs in registers.
 // Layout trick (cdna_hip_programming.md s3, "an accumulator tile as the next MFMA's operand"):
@@ -23,9 +24,9 @@ __device__ __forceinline__ int lds_off(int r, int d) {
 // stage rows [0, rows_alloc) x HE of one head into LDS; rows >= S are zero-filled
 template <int HE>
 __device__ __forceinline__ void stage_head(unsigned char* lds, const bf16* __restrict__ src, size_t ld,
-                                           int S, int rows_alloc, int lane) {
+                                           int S, int rows_alloc, int tid, int nthreads) {
   constexpr int CPR = HE / 8;  // 16-B chunks per row
-  for (int idx = lane; idx < rows_alloc * CPR; idx += 64) {
+  for (int idx = tid; idx < rows_alloc * CPR; idx += nthreads) {
     const int r = idx / CPR, c = idx - r * CPR;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r < S) v = *(const u32x4*)(src + (size_t)r * ld + 8 * c);
@@ -76,88 +77,77 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 template <int HE, int NT>
-__global__ __launch_bounds__(64) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                         float* __restrict__ lse, int S, int H, float scale) {
+__global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                              float* __restrict__ lse, int S, int H, float scale) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
   __shared__ __attribute__((aligned(16))) unsigned char vl[RP * HE * 2];
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6;  // wave qt owns query rows 16*qt .. 16*qt+15
+  const int g = lane >> 4, li = lane & 15;
   const int E = H * HE;
   const size_t ld = 3 * (size_t)E;
   const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
   const bf16* kb = qb + E;
   const bf16* vb = qb + 2 * E;
 
-  stage_head<HE>(vl, vb, ld, S, RP, lane);
+  stage_head<HE>(vl, vb, ld, S, RP, tid, 64 * NT);
 
-  bf16x8 qf[NT][KS];
+  bf16x8 qf[KS];
 #pragma unroll
-  for (int qt = 0; qt < NT; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = gfrag(qb, ld, 16 * qt, ks, S, lane);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag(qb, ld, 16 * qt, ks, S, lane);
 
-  f32x4 sc[NT][NT];  // [kt][qt]: rows = keys 16kt+4g+r, col = query 16qt+li
+  f32x4 sc[NT];  // [kt]: rows = keys 16kt+4g+r, col = query 16qt+li
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
-    bf16x8 kf[KS];
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = gfrag(kb, ld, 16 * kt, ks, S, lane);
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a = vg_mfma(kf[ks], qf[qt][ks], a);
-      sc[kt][qt] = a;
-    }
+    for (int ks = 0; ks < KS; ++ks) a = vg_mfma(gfrag(kb, ld, 16 * kt, ks, S, lane), qf[ks], a);
+    sc[kt] = a;
   }
-  __syncthreads();  // V image complete
-
+  const int q = 16 * qt + li;
+  float m = -INFINITY;
 #pragma unroll
-  for (int qt = 0; qt < NT; ++qt) {
-    const int q = 16 * qt + li;
-    float m = -INFINITY;
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * kt + 4 * g + r;
-        const float s = (key < S) ? sc[kt][qt][r] * scale : -INFINITY;
-        sc[kt][qt][r] = s;
-        m = fmaxf(m, s);
-      }
-    m = group_max(m);
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(sc[kt][qt][r] - m);
-        sc[kt][qt][r] = p;
-        l += p;
-      }
-    l = group_sum(l);
-    const float inv_l = 1.0f / l;
-    if (g == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __logf(l);
-
-    f32x4 oa[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) oa[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < KP; ++u) {
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 pf = pack_pair(sc[2 * u][qt], (2 * u + 1 < NT) ? sc[(2 * u + 1 < NT) ? 2 * u + 1 : 0][qt] : zero);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma(lfrag_tr<HE>(vl, u, 16 * dt, lane), pf, oa[dt]);
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * g + r;
+      const float sv = (key < S) ? sc[kt][r] * scale : -INFINITY;
+      sc[kt][r] = sv;
+      m = fmaxf(m, sv);
     }
-    if (q < S) {
-      bf16* op = o + ((size_t)b * S + q) * E + h * HE + 4 * g;
+  m = group_max(m);
+  float l = 0.f;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        bf16x4 w;
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = vg_f2bf(oa[dt][r] * inv_l);
-        *(bf16x4*)(op + 16 * dt) = w;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(sc[kt][r] - m);
+      sc[kt][r] = p;
+      l += p;
+    }
+  l = group_sum(l);
+  const float inv_l = 1.0f / l;
+  if (g == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __logf(l);
+
+  __syncthreads();  // V image complete
+  f32x4 oa[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oa[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < KP; ++u) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 pf = pack_pair(sc[2 * u], (2 * u + 1 < NT) ? sc[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma(lfrag_tr<HE>(vl, u, 16 * dt, lane), pf, oa[dt]);
+  }
+  if (q < S) {
+    bf16* op = o + ((size_t)b * S + q) * E + h * HE + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = vg_f2bf(oa[dt][r] * inv_l);
+      *(bf16x4*)(op + 16 * dt) = w;
     }
   }
 }
@@ -166,7 +156,7 @@ __global__ __launch_bounds__(64) void vg_attn_fwd_kernel(const bf16* __restrict_
 // S orientation (lane = key) and yields dK, dV.  Recomputing the 65x65 tile in both orientations
 // costs 2 x 75 extra MFMAs per head and removes every register transpose.
 template <int HE, int NT>
-__global__ __launch_bounds__(64) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, int S, int H, float scale) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
@@ -176,7 +166,8 @@ __global__ __launch_bounds__(64) void vg_attn_bwd_kernel(const bf16* __restrict_
   unsigned char* l1 = sm + IMG;
   float* dl = (float*)(sm + 2 * IMG);  // delta[q] = sum_d dO*O
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
+  const int g = lane >> 4, li = lane & 15;
   const int E = H * HE;
   const size_t ld = 3 * (size_t)E;
   const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
@@ -189,12 +180,12 @@ __global__ __launch_bounds__(64) void vg_attn_bwd_kernel(const bf16* __restrict_
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
   // ---------------- phase A: K, V in LDS; loop over query tiles -> dQ ----------------------
-  stage_head<HE>(l0, kb, ld, S, RP, lane);
-  stage_head<HE>(l1, vb, ld, S, RP, lane);
-  for (int i = lane; i < RP; i += 64) dl[i] = 0.f;
+  stage_head<HE>(l0, kb, ld, S, RP, tid, 64 * NT);
+  stage_head<HE>(l1, vb, ld, S, RP, tid, 64 * NT);
+  for (int i = tid; i < RP; i += 64 * NT) dl[i] = 0.f;
   __syncthreads();
-#pragma unroll 1
-  for (int qt = 0; qt < NT; ++qt) {
+  {
+    const int qt = wv;
     const int q = 16 * qt + li;
     bf16x8 qf[KS], dof[KS];
     float dpart = 0.f;
@@ -247,11 +238,11 @@ __global__ __launch_bounds__(64) void vg_attn_bwd_kernel(const bf16* __restrict_
   }
   __syncthreads();
   // ---------------- phase B: Q, dO in LDS; loop over key tiles -> dK, dV ---------------------
-  stage_head<HE>(l0, qb, ld, S, RP, lane);
-  stage_head<HE>(l1, dob, (size_t)E, S, RP, lane);
+  stage_head<HE>(l0, qb, ld, S, RP, tid, 64 * NT);
+  stage_head<HE>(l1, dob, (size_t)E, S, RP, tid, 64 * NT);
   __syncthreads();
-#pragma unroll 1
-  for (int kt = 0; kt < NT; ++kt) {
+  {
+    const int kt = wv;
     const int key = 16 * kt + li;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -309,13 +300,13 @@ __global__ __launch_bounds__(64) void vg_attn_bwd_kernel(const bf16* __restrict_
 
 template <int HE, int NT>
 static int launch_fwd(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT>), dim3(B * H), dim3(64), 0, st, qkv, o, lse, S, H, scale);
+  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale);
   return (int)hipGetLastError();
 }
 template <int HE, int NT>
 static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
                       int S, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT>), dim3(B * H), dim3(64), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale);
+  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale);
   return (int)hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ extern "C" int vg_layernorm_bwd(const void* dy, const void* x, const float* mean
                                 const void* gres, void* dx, float* part, int R, int E, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !part) return -1;
   return vg_ln_bwd_launch((const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)gres, (bf16*)dx, part, R, E,
-                          (hipStream_t)stream);
+                          nullptr, 0, 0, 1.f, nullptr, (hipStream_t)stream);
 }
 extern "C" int vg_sln_fwd(const void* h, int h_bcast_rows, const void* w, const float* lw, const float* lb, const float* gs,
                           const float* bs, void* y, float* mean, float* rstd, int R, int E, float eps, void* stream) {
@@ -58,7 +58,7 @@ extern "C" int vg_sln_bwd(const void* dy, const void* h, int h_bcast_rows, const
                           float* dw_acc, int dw_accumulate, float* part, int R, int E, void* stream) {
   if (!dy || !h || !w || !mean || !rstd || !lw || !lb || !gs || !bs || !dh || !dw_acc || !part) return -1;
   return vg_sln_bwd_launch((const bf16*)dy, (const bf16*)h, h_bcast_rows, (const bf16*)w, mean, rstd, lw, lb, gs, bs,
-                           (const bf16*)gres, (bf16*)dh, dw_acc, dw_accumulate, part, R, E, (hipStream_t)stream);
+                           (const bf16*)gres, (bf16*)dh, dw_acc, dw_accumulate, part, R, E, nullptr, 0, 0, 1.f, nullptr, (hipStream_t)stream);
 }
 extern "C" int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
                              float* d3, int n3, int accumulate, void* stream) {
@@ -69,6 +69,15 @@ extern "C" int vg_colsum_bf16_parts(int R) { return vg_colsum_bf16_nparts(R); }
 extern "C" int vg_colsum_bf16(const void* X, long long ld, int R, int N, float* part_ws, float* dst, int accumulate, void* stream) {
   if (!X || !part_ws || !dst) return -1;
   return vg_colsum_bf16_launch((const bf16*)X, ld, R, N, part_ws, dst, accumulate, (hipStream_t)stream);
+}
+extern "C" int vg_dropout_apply(const void* x, void* y, long long n, float p, unsigned long long seed, int site,
+                                const unsigned* step_dev, void* stream) {
+  if (!x || !y || n < 1 || p < 0.f || p >= 1.f) return -1;
+  int t = (int)lrintf(p * 256.f); if (t > 255) t = 255;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  return vg_dropout_apply_launch((const bf16*)x, (bf16*)y, n, (unsigned)t, (unsigned)(z ^ (z >> 32)), t ? 256.f / (256.f - t) : 1.f,
+                                 step_dev, (hipStream_t)stream);
 }
 extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;

@@ -39,13 +39,33 @@ __global__ __launch_bounds__(256) void vg_unpatchify_kernel(const bf16* __restri
   for (int px = 0; px < P; ++px) dst[px] = src[px];
 }
 
-// ---- CLS rows of the token matrix: x[b*S + 0, :] = cls ------------------------------------------
+// ---- CLS rows of the token matrix: x[b*S + 0, :] = dropout(cls) (the embedding dropout, modules.py:99) ----
 __global__ __launch_bounds__(256) void vg_fill_cls_kernel(bf16* __restrict__ x, const float* __restrict__ cls, int B, int S,
-                                                          int E) {
+                                                          int E, unsigned dthr, unsigned dkey0, float dscale, const unsigned* __restrict__ dstep) {
+  const unsigned dkey = vg_drop_key(dkey0, dstep);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * E) return;
   const int b = i / E, e = i - b * E;
-  x[(size_t)b * S * E + e] = vg_f2bf(cls[e]);
+  float v = cls[e];
+  if (dthr) {
+    const unsigned idx = (unsigned)(b * S) * (unsigned)E + (unsigned)e;
+    v *= vg_drop_factor(vg_drop_word(dkey, idx >> 2), idx & 3, dthr, dscale);
+  }
+  x[(size_t)b * S * E + e] = vg_f2bf(v);
+}
+// y[i] = x[i] * mask(i) / keep   (gradient of a dropout site where no producer kernel can fuse it; n % 4 == 0)
+__global__ __launch_bounds__(256) void vg_dropout_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long n,
+                                                               unsigned dthr, unsigned dkey0, float dscale,
+                                                               const unsigned* __restrict__ dstep) {
+  const unsigned dkey = vg_drop_key(dkey0, dstep);
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const bf16x4 v = *(const bf16x4*)(x + i4);
+  const unsigned wd = vg_drop_word(dkey, (unsigned)(i4 >> 2));
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = vg_f2bf(vg_bf2f(v[j]) * vg_drop_factor(wd, j, dthr, dscale));
+  *(bf16x4*)(y + i4) = o;
 }
 // ---- gather / scatter of row subsets ---------------------------------------------------------
 // out[(b*n_take + j), :] = in[(b*S + first + j), :]      (16 B per thread)
@@ -258,8 +278,15 @@ int vg_unpatchify_launch(const bf16* dA, bf16* dimg, int B, int C, int IH, int P
   hipLaunchKernelGGL(vg_unpatchify_kernel, dim3(nblk(total)), dim3(256), 0, st, dA, dimg, B, C, IH, P);
   return (int)hipGetLastError();
 }
-int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, hipStream_t st) {
-  hipLaunchKernelGGL(vg_fill_cls_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, x, cls, B, S, E);
+int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(vg_fill_cls_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, x, cls, B, S, E, dthr, dkey, dscale, dstep);
+  return (int)hipGetLastError();
+}
+int vg_dropout_apply_launch(const bf16* x, bf16* y, long long n, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
+                            hipStream_t st) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(vg_dropout_apply_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, x, y, n, dthr, dkey, dscale, dstep);
   return (int)hipGetLastError();
 }
 int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int n_take, int E, hipStream_t st) {

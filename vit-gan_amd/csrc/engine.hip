@@ -108,10 +108,25 @@ static VgGemmProb mk(const bf16* A, int lda, const bf16* Bm, int ldb, int M, int
   p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
   return p;
 }
+struct Drop { unsigned thr; float scale; unsigned long long seed; const unsigned* step; };
+static Drop mk_drop(float p, unsigned long long seed, const unsigned* step) {
+  Drop d; int t = (int)lrintf(p * 256.f); if (t < 0) t = 0; if (t > 255) t = 255;
+  d.thr = (unsigned)t; d.scale = t ? 256.f / (256.f - (float)t) : 1.f; d.seed = seed; d.step = step; return d;
+}
+static unsigned site_key(const Drop& d, int site) {  // splitmix64 of (seed, site) folded to 32 bits
+  unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  return (unsigned)(z ^ (z >> 32));
+}
+static void set_drop(VgGemmProb& p, const Drop& d, int site, int post) {
+  if (!d.thr) return;
+  p.drop_thresh = d.thr; p.drop_key = site_key(d, site); p.drop_scale = d.scale; p.drop_post = post; p.drop_step = d.step;
+}
 // forward Linear: C = act(A W^T + b) (+res)
 static int lin_fwd(const bf16* A, int K, const bf16* W, const float* bias, bf16* C, int M, int N, int act, float ascale,
-                   const bf16* res, bf16* pre_bf16, float* pre_f32, hipStream_t st) {
+                   const bf16* res, bf16* pre_bf16, float* pre_f32, hipStream_t st, const Drop* drop = nullptr, int site = 0) {
   VgGemmProb p = mk(A, K, W, K, M, N, K);
+  if (drop) set_drop(p, *drop, site, 0);
   p.C = C; p.ldc = N; p.bias = bias; p.act = act; p.act_scale = ascale;
   p.res = res; p.ldr = N; p.C2 = pre_bf16; p.ldc2 = N;
   if (pre_f32) { p.pre_f32 = 1; p.Cf = pre_f32; p.ldcf = N; }
@@ -148,7 +163,7 @@ static inline long long tiles128(long long m, long long n) { return ((m + 127) /
 struct VitWs {
   bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *z1, *a1, *xcls, *hcls, *th;
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf;
-  bf16 *g[3], *dz1, *dxn, *dao, *dqkv, *gp, *dA, *dzh, *dhcls, *dxcls;
+  bf16 *g[3], *gm[2], *dz1, *dxn, *dao, *dqkv, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *tok_sum, *slab;
 };
 static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
@@ -171,6 +186,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   w.mean2 = c.take<float>(L * M); w.rstd2 = c.take<float>(L * M);
   w.meanf = c.take<float>(B); w.rstdf = c.take<float>(B);
   for (int i = 0; i < 3; ++i) w.g[i] = c.take<bf16>(M * E);
+  for (int i = 0; i < 2; ++i) w.gm[i] = c.take<bf16>(M * E);  // dropout-masked copies of residual-stream gradients
   w.dz1 = c.take<bf16>(M * rE);
   w.dxn = c.take<bf16>(M * E);
   w.dao = c.take<bf16>(M * E);
@@ -205,6 +221,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   VitWs w; carve_vit(d, B, ws, w);
   const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb;
   const size_t ME = (size_t)M * E;
+  const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);  // sites: 0 embedding, 1+2l attention branch, 2+2l MLP branch
 
   // patch embedding (src/v2/modules.py:82-98): gather -> GEMM(+bias +pos, rows remapped past CLS) ; CLS row
   VG_TRY(vg_patchify_launch(img, img_is_bf16, w.Apatch, B, d.C, d.IH, d.P, st));
@@ -212,9 +229,10 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     VgGemmProb p = mk(w.Apatch, Kp, Pb + lay.conv_w, Kp, B * NP, E, Kp);
     p.C = w.X; p.ldc = E; p.bias = P + lay.conv_b; p.resf = P + lay.pos; p.res_period = NP;
     p.row_in_per = NP; p.row_out_per = S; p.row_out_off = 1;
+    set_drop(p, dr, 0, 1);
     VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
   }
-  VG_TRY(vg_fill_cls_launch(w.X, P + lay.cls, B, S, E, st));
+  VG_TRY(vg_fill_cls_launch(w.X, P + lay.cls, B, S, E, dr.thr, site_key(dr, 0), dr.scale, dr.step, st));
 
   for (int l = 0; l < d.L; ++l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
@@ -230,12 +248,12 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
                             w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
     VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
-    VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st));
+    VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
     VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
                             w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st));
     VG_TRY(lin_fwd(a1, rE, Pb + lo + lay.w2, P + lo + lay.b2, w.X + (size_t)(l + 1) * ME, M, E, VG_ACT_NONE, 0.f, xmid,
-                   nullptr, nullptr, st));
+                   nullptr, nullptr, st, &dr, 2 + 2 * l));
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
@@ -264,6 +282,12 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
   const size_t ME = (size_t)M * E;
   const int lnparts = vg_ln_bwd_nparts(M);
+  const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
+  const bool drop = dr.thr != 0;
+  // with dropout, the gradient entering a dropped branch is the residual-stream gradient times the mask:
+  // gm2 (MLP branch, masked g) and gm1 (attention branch, masked gmid) are second outputs of the LN backward
+  bf16* const gm2buf = w.gm[0];
+  bf16* const gm1buf = w.gm[1];
 
   bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   const int layers_done = stage_begin > 0 ? stage_begin - 1 : 0;  // blocks already processed by earlier calls
@@ -280,10 +304,11 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
   }
   VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
-  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, st));
+  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st));
   if (want_wgrad)
     VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
   VG_TRY(vg_scatter_cls_launch(w.dxcls, g, B, S, E, st));
+  if (drop) VG_TRY(vg_dropout_apply_launch(g, gm2buf, (long long)M * E, dr.thr, site_key(dr, 2 + 2 * (d.L - 1)), dr.scale, dr.step, st));
   }
 
   for (int l = d.L - 1; l >= 0; --l) {
@@ -299,16 +324,19 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* xn2 = w.xn2 + (size_t)l * ME;
     const bf16* z1 = w.z1 + (size_t)l * M * rE;
     const bf16* a1 = w.a1 + (size_t)l * M * rE;
-    // fc2 bias grad = colsum(g)
-    if (want_wgrad && !have_g_colsum) VG_TRY(vg_colsum_bf16_launch(g, E, M, E, w.part_cs, G + lo + lay.b2, 1, st));
-    // d a1 = g W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
-    VG_TRY(lin_dgrad(g, Pb + lo + lay.w2, w.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
+    const bf16* gb2 = drop ? gm2buf : g;  // gradient w.r.t. the fc2 output (before dropout2)
+    // fc2 bias grad = colsum(gb2)
+    if (want_wgrad && !have_g_colsum) VG_TRY(vg_colsum_bf16_launch(gb2, E, M, E, w.part_cs, G + lo + lay.b2, 1, st));
+    // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, w.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
     if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dz1, rE, M, rE, w.part_cs, G + lo + lay.b1, 1, st));
     VG_TRY(lin_dgrad(w.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, gmid, w.part, M, E, st));
+    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, gmid, w.part, M, E,
+                            drop ? gm1buf : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    const bf16* gb1 = drop ? gm1buf : gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     if (want_wgrad)
       VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0, 1, st));
-    VG_TRY(lin_dgrad(gmid, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, w.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
     if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dqkv, 3 * E, M, 3 * E, w.part_cs, G + lo + lay.bqkv, 1, st));
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
@@ -318,13 +346,16 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       const int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
       VgGemmProb pr[4];
       pr[0] = wg(w.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
-      pr[1] = wg(gmid, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
+      pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
       pr[2] = wg(w.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
-      pr[3] = wg(g, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
+      pr[3] = wg(gb2, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
       VG_TRY(vg_gemm_launch(pr, 4, VG_TN, st));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
     }
-    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gin, w.part, M, E, st));
+    // second output: the same gradient masked for the dropout it meets next (block l-1's MLP branch, or the
+    // embedding dropout below block 0); the wgrad launch above has consumed gm2buf, so it can be rewritten
+    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gin, w.part, M, E,
+                            drop ? gm2buf : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
     if (want_wgrad) {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
       VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0, 1, st));
@@ -335,6 +366,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
 
   if (stage_end < d.L + 2) return 0;
   // ---- patch embedding ----
+  if (drop) g = gm2buf;  // dL/dX[0] masked by the embedding dropout (second output of block 0's LN1 backward)
   if (want_wgrad) {
     VG_TRY(vg_batch_sum_launch(g, w.tok_sum, B, S, E, st));
     VG_TRY(vg_embed_small_grads_launch(w.tok_sum, G + lay.cls, G + lay.pos, G + lay.conv_b, S, E, st));
@@ -366,7 +398,7 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
 struct GenWs {
   bf16 *zb, *wmod, *s1, *qkv, *cat, *htmp, *s2, *hout, *sf, *y1;
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf, *zf1, *zf2;
-  bf16 *g[3], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
+  bf16 *g[3], *gm[2], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
   float *dw_acc, *part, *part_cs, *emb_sum, *slab;
 };
 static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
@@ -390,6 +422,7 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.zf1 = c.take<float>(R * d.O);
   w.zf2 = c.take<float>(R * d.CW);
   for (int i = 0; i < 3; ++i) w.g[i] = c.take<bf16>(R * E);
+  for (int i = 0; i < 2; ++i) w.gm[i] = c.take<bf16>(R * E);
   w.dz2 = c.take<bf16>(R * d.CW);
   w.dz1 = c.take<bf16>(R * d.O);
   w.ds = c.take<bf16>(R * E);
@@ -424,6 +457,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb;
   const size_t RE = (size_t)R * E;
   const float scale = 1.0f / sqrtf((float)E);  // softmax(q.k / sqrt(H*hd)), src/v1/attention.py:51,90
+  const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);  // sites: 100+2l after output_linear, 101+2l inside the MLP
 
   // mapping network (generator.py:59-61): w = Linear(z) viewed [B*T, E]
   VG_TRY(vg_cast_f32_bf16_launch(z, w.zb, (long long)B * d.Z, st));
@@ -446,11 +480,13 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
       VgGemmProb p = mk(cat, E, Pb + lo + lay.wo, E, R, E, E);
       p.C = htmp; p.ldc = E; p.bias = P + lo + lay.bo;
       if (l == 0) { p.resf = P + lay.emb; p.res_period = T; } else { p.res = h; p.ldr = E; }
+      set_drop(p, dr, 100 + 2 * l, 0);  // attention_dropout(msha(...)) + h, transformer.py:86
       VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
     }
     VG_TRY(vg_sln_fwd_launch(htmp, 0, w.wmod, P + lo + lay.sln2_w, P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1,
                              s2, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, R, E, 1e-5f, st));
-    VG_TRY(lin_fwd(s2, E, Pb + lo + lay.wm, P + lo + lay.bm, w.hout + (size_t)l * RE, R, E, VG_ACT_NONE, 0.f, htmp, nullptr, nullptr, st));
+    VG_TRY(lin_fwd(s2, E, Pb + lo + lay.wm, P + lo + lay.bm, w.hout + (size_t)l * RE, R, E, VG_ACT_NONE, 0.f, htmp, nullptr, nullptr, st,
+                   &dr, 101 + 2 * l));  // Sequential(Linear, Dropout) + htmp, muilti_layer_perceptron.py:26-28
   }
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
@@ -472,6 +508,10 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   const size_t RE = (size_t)R * E;
   const float scale = 1.0f / sqrtf((float)E);
   const int parts = vg_ln_bwd_nparts(R);
+  const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
+  const bool drop = dr.thr != 0;
+  bf16* const gm2buf = w.gm[0];  // g masked for the MLP-branch dropout it meets next
+  bf16* const gm1buf = w.gm[1];  // gmid masked for the attention-branch dropout
 
   // SIREN output layers (siren.py:44-45): y = sin(w0 z)  ->  dz = dy * w0 cos(w0 z)
   VG_TRY(vg_sin_grad_launch((const bf16*)d_img, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
@@ -494,7 +534,7 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
-                           nullptr, g, w.dw_acc, 0, w.part, R, E, st));
+                           nullptr, g, w.dw_acc, 0, w.part, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
   {
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
     VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2, 1, st));
@@ -508,13 +548,16 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     const bf16* cat = w.cat + (size_t)l * RE;
     const bf16* htmp = w.htmp + (size_t)l * RE;
     const bf16* s2 = w.s2 + (size_t)l * RE;
-    // hout = mlp(s2) + htmp  (transformer.py:87; MLP is a single Linear, muilti_layer_perceptron.py:37-42)
-    VG_TRY(lin_dgrad(g, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
+    // hout = drop(mlp(s2)) + htmp  (transformer.py:87; MLP is a single Linear, muilti_layer_perceptron.py:37-42)
+    const bf16* gb2 = drop ? gm2buf : g;
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_sln_bwd_launch(w.ds, htmp, 0, w.wmod, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w,
-                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part, R, E, st));
+                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part, R, E,
+                             drop ? gm1buf : nullptr, dr.thr, site_key(dr, 100 + 2 * l), dr.scale, dr.step, st));
+    const bf16* gb1 = drop ? gm1buf : gmid;
     VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
                                 G + lo + lay.sln2_s, 2, 1, st));
-    VG_TRY(lin_dgrad(gmid, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, st));
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     {
@@ -522,13 +565,14 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
       const int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
       VgGemmProb pr[3];
       pr[0] = wg(w.dqkv, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
-      pr[1] = wg(gmid, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);
-      pr[2] = wg(g, E, s2, E, R, w.slab + lay.wm, lay.layer_weights, splits);
+      pr[1] = wg(gb1, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);
+      pr[2] = wg(gb2, E, s2, E, R, w.slab + lay.wm, lay.layer_weights, splits);
       VG_TRY(vg_gemm_launch(pr, 3, VG_TN, st));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
     }
     VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
-                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part, R, E, st));
+                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part, R, E,
+                             (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
     float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
     VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2, 1, st));
     bf16* t = g; g = gin; gin = t;

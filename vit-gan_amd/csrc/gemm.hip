@@ -120,7 +120,7 @@ __device__ __forceinline__ float apply_act(float scale, float v) {
 
 // FEAT: epilogue features COMPILED IN (each still tests its runtime pointer); the launcher picks the
 // smallest compiled superset so the common epilogues carry no dead address arithmetic.
-enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31 };
+enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31, F_DROP = 32 };
 
 // Occupancy is the lever on MI355X for these short-K GEMMs (measured: 16 waves/CU beats a deeper DMA ring at
 // 8-12 waves/CU by 25-40 %): WM=2 -> 2-stage ring (32 KiB) x 4 workgroups/CU, WM=4 -> 3-stage ring (72 KiB) x 2
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
   const float* const eZf = P.Zf; const int eldzf = P.ldzf;
   const float ascale = P.act_scale;
   const int epre = P.pre_f32, rip = P.row_in_per, rop = P.row_out_per, roo = P.row_out_off;
+  const unsigned dthr = P.drop_thresh, dkey = vg_drop_key(P.drop_key, P.drop_step); const float dscale = P.drop_scale; const int dpost = P.drop_post;
 
   const int local = bid - P.tile_start;
   const int tiles_mn = P.tiles_m * P.tiles_n;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
   constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD);
   constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
   constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
-  constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0;
+  constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0, HAS_DROP = (FEAT & F_DROP) != 0;
   constexpr bool PRE_BF = NEED_ZBF || HAS_RES, PRE_F = NEED_ZF || HAS_RESF;
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
   bf16x8 pre_bf[PRE_BF ? 8 : 1];
@@ -367,6 +368,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = apply_act<ACT>(ascale, v[r]);
       }
+      unsigned dw0 = 0, dw1 = 0;
+      if (HAS_DROP && dthr) {
+        const unsigned i4 = (unsigned)(mo * eN + n) >> 2;
+        dw0 = vg_drop_word(dkey, i4); dw1 = vg_drop_word(dkey, i4 + 1);
+        if (!dpost) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] *= vg_drop_factor(dw0, r, dthr, dscale); v[r + 4] *= vg_drop_factor(dw1, r, dthr, dscale); }
+        }
+      }
       if (HAS_RES && !NEED_ZBF && eres) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
@@ -374,6 +384,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
       if (HAS_RESF && !NEED_ZF && eresf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] += pre_f0[PRE_F ? q : 0][r]; v[r + 4] += pre_f1[PRE_F ? q : 0][r]; }
+      }
+      if (HAS_DROP && dthr && dpost) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] *= vg_drop_factor(dw0, r, dthr, dscale); v[r + 4] *= vg_drop_factor(dw1, r, dthr, dscale); }
       }
       if (eC) {
         bf16x8 o;
@@ -458,13 +472,18 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     if (q.row_in_per > 0) feat |= F_REMAP;
     if (q.C2) feat |= F_C2;
     if (q.pre_f32) feat |= F_PREF32;
+    if (q.drop_thresh) feat |= F_DROP;
   }
+  if ((feat & F_DROP) && ((feat & (F_C2 | F_PREF32)) || mode != VG_NT)) return -4;
   if (mode == VG_NT) {
     if (act == VG_ACT_NONE) {
       if (feat == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, 0);
       else if (feat == F_RES) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RES);
+      else if (feat & F_DROP) VG_BY_WM(VG_NT, VG_ACT_NONE, F_DROP | F_RES | F_RESF | F_REMAP);  // training-mode dropout sites
       else if ((feat & ~(F_RESF | F_REMAP)) == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RESF | F_REMAP);
       else VG_BY_WM(VG_NT, VG_ACT_NONE, F_ALL);
+    } else if (feat & F_DROP) {
+      return -4;  // dropout is only fused behind a plain Linear (the reference's three sites)
     } else if (act == VG_ACT_GELU) {
       if ((feat & ~F_C2) == 0) VG_BY_WM(VG_NT, VG_ACT_GELU, F_C2);
       else VG_BY_WM(VG_NT, VG_ACT_GELU, F_ALL);
@@ -477,7 +496,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
       return -4;
     }
   } else if (mode == VG_NN) {
-    if (feat != 0) return -4;  // dgrad epilogues take no residual / second output
+    if (feat != 0) return -4;  // dgrad epilogues take no residual / second output / dropout
     switch (act) {
       case VG_ACT_NONE: VG_BY_WM(VG_NN, VG_ACT_NONE, 0); break;
       case VG_ACT_MUL_GELU_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_GELU_GRAD, 0); break;

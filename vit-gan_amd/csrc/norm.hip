@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
                                                         bf16* __restrict__ dx, float* __restrict__ part, int part_w,
                                                         const bf16* __restrict__ wmod, const float* __restrict__ gs,
                                                         const float* __restrict__ bs, float* __restrict__ dw_acc,
-                                                        int dw_accumulate, int R, int E) {
+                                                        int dw_accumulate, int R, int E, bf16* __restrict__ dxm,
+                                                        unsigned dthr, unsigned dkey0, float dscale,
+                                                        const unsigned* __restrict__ dstep) {
+  const unsigned dkey = vg_drop_key(dkey0, dstep);
   __shared__ float red[4 * 64 * LN_MAX_PER_LANE];  // [wave][E]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float ag[2 * NPL], ab[2 * NPL], ac[2 * NPL];
@@ -176,6 +179,15 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
         }
         bf16x2 o; o[0] = vg_f2bf(o0); o[1] = vg_f2bf(o1);
         oxr[lane + 64 * i] = o;
+        if (dxm) {  // gradient entering the dropped branch: dx * mask / keep  (same mask as the forward epilogue)
+          const unsigned idx = (unsigned)row * (unsigned)E + 2u * (lane + 64 * i);
+          const unsigned wd = vg_drop_word(dkey, idx >> 2);
+          bf16x2 om;
+          om[0] = vg_f2bf(vg_bf2f(o[0]) * vg_drop_factor(wd, idx & 3, dthr, dscale));
+          om[1] = vg_f2bf(vg_bf2f(o[1]) * vg_drop_factor(wd, (idx & 3) + 1, dthr, dscale));
+          ((bf16x2*)(dxm + (size_t)row * E))[lane + 64 * i] = om;
+          o = om;
+        }
         ac[2 * i] += vg_bf2f(o[0]); ac[2 * i + 1] += vg_bf2f(o[1]);
       }
   }
@@ -281,11 +293,12 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 }
 int vg_ln_bwd_nparts(int R) { const int n = (R + 7) / 8; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
-                     const bf16* gres, bf16* dx, float* part, int R, int E, hipStream_t st) {
+                     const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
+                     float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
 #define LN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
-                     (const float*)nullptr, (float*)nullptr, 0, R, E)
+                     (const float*)nullptr, (float*)nullptr, 0, R, E, dxm, dthr, dkey, dscale, dstep)
   switch (E >> 7) {
     case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
     case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; case 8: LN_BWD(8); break;
@@ -297,10 +310,10 @@ int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const flo
 int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
                       const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
-                      hipStream_t st) {
+                      bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
 #define SLN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
-                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, E)
+                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, E, dhm, dthr, dkey, dscale, dstep)
   switch (E >> 7) {
     case 1: SLN_BWD(1); break; case 2: SLN_BWD(2); break; case 3: SLN_BWD(3); break; case 4: SLN_BWD(4); break;
     case 5: SLN_BWD(5); break; case 6: SLN_BWD(6); break; case 7: SLN_BWD(7); break; case 8: SLN_BWD(8); break;

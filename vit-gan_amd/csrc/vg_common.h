@@ -72,12 +72,22 @@ __device__ __forceinline__ float vg_tanh(float x) {  // 1 - 2/(exp(2x)+1), satur
   return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
 
-// Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless, so the
-// backward pass regenerates the identical mask from (seed, element index).
-__device__ __forceinline__ uint32_t vg_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+// Counter-based dropout: element e of a dropped tensor (row-major, linear index e) is kept iff byte (e & 3)
+// of vg_drop_word(key, e >> 2) is >= thresh (thresh = round(p * 256), so p is quantised to 1/256 and the
+// survivors are scaled by 256 / (256 - thresh)).  Stateless: forward epilogues and backward kernels
+// regenerate the identical mask from (key, index); key = host hash of (seed, dropout site).
+__device__ __forceinline__ uint32_t vg_drop_word(uint32_t key, uint32_t idx4) {
+  uint32_t x = idx4 * 0x9E3779B1u + key;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+// key actually used by a launch: host key mixed with a device-resident step counter (so a replayed hipGraph
+// draws a fresh mask every step); dstep == nullptr leaves the host key unchanged
+__device__ __forceinline__ uint32_t vg_drop_key(uint32_t key, const unsigned* __restrict__ dstep) {
+  return dstep ? key ^ (dstep[0] * 0x9E3779B1u + 0x7F4A7C15u) : key;
+}
+__device__ __forceinline__ float vg_drop_factor(uint32_t word, int e, uint32_t thresh, float scale) {
+  return (((word >> (8 * (e & 3))) & 0xFFu) >= thresh) ? scale : 0.f;
 }

@@ -35,6 +35,9 @@ struct VgGemmProb {
   int act; float act_scale;
   int pre_f32;                 // store bias-added pre-activation to Cf (fp32) when set (NT only)
   int row_in_per, row_out_per, row_out_off;  // output row remap: (m/in)*out + off + m%in  (0 = none)
+  // dropout on the output (NT only): drop_thresh = round(p*256) (0 = off); applied after bias/activation and BEFORE
+  // the residual (drop_post = 0: x + drop(y)) or after every addend (drop_post = 1: drop(y + pos)); index = row*N + col
+  unsigned drop_thresh, drop_key; float drop_scale; int drop_post; const unsigned* drop_step;
   // filled by the launcher
   int tiles_m, tiles_n, tile_start, k_per_split;
 };

@@ -14,11 +14,12 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
                       hipStream_t st);
 int vg_ln_bwd_nparts(int R);
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
-                     const bf16* gres, bf16* dx, float* part, int R, int E, hipStream_t st);
+                     const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
+                     float dscale, const unsigned* dstep, hipStream_t st);
 int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
                       const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
-                      hipStream_t st);
+                      bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st);
 int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
                          float* d3, int n3, int accumulate, hipStream_t st);
 int vg_colsum_bf16_nparts(int R);
@@ -27,7 +28,10 @@ int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part
 
 int vg_patchify_launch(const void* img, int img_is_bf16, bf16* A, int B, int C, int IH, int P, hipStream_t st);
 int vg_unpatchify_launch(const bf16* dA, bf16* dimg, int B, int C, int IH, int P, hipStream_t st);
-int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, hipStream_t st);
+int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
+                       hipStream_t st);
+int vg_dropout_apply_launch(const bf16* x, bf16* y, long long n, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
+                            hipStream_t st);
 int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int n_take, int E, hipStream_t st);
 int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st);
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st);

@@ -37,6 +37,7 @@ class GanEngine:
     def __init__(self, discriminator, generator: SirenGenerator, batch: int, loss: str = "ns",
                  lr_d: float = 5e-4, lr_g: float = 5e-4, weight_decay: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
+                 d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
                  process_group: Optional["dist.ProcessGroup"] = None):
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
@@ -48,6 +49,10 @@ class GanEngine:
         if loss not in LOSS_KINDS:
             raise ValueError(f"loss must be one of {sorted(LOSS_KINDS)}")
         self.B, self.kind = int(batch), LOSS_KINDS[loss]
+        # dropout probabilities: default = what the modules would apply in their current train/eval mode
+        self.p_d = float(vit._dropout_p if vit.training else 0.0) if d_dropout is None else float(d_dropout)
+        self.p_g = float(generator.dropout_p if generator.training else 0.0) if g_dropout is None else float(g_dropout)
+        self.seed = int(seed)
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
         self.pg = process_group
@@ -82,9 +87,13 @@ class GanEngine:
     # ------------------------------------------------------------------------------------------
     def _nets(self):
         fd, fg = self.vit._flat, self.gen._flat
-        nd = _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr())
-        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr())
-        return nd, ng
+        # masks: host seed (fixed per pass) mixed on the device with the step counter, so a replayed hipGraph
+        # still draws fresh masks; pass A = [real;fake] (or real), B = fake, C = generator pass through D
+        step_ptr = self.step_t.data_ptr()
+        mk = lambda i: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(),  # noqa: E731
+                                     self.p_d, self.seed * 8 + i, step_ptr)
+        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr)
+        return (mk(0), mk(1), mk(2)), ng
 
     def _d_backward(self, nd, n_img: int, dl, want_w: int, dimg, st) -> None:
         """D backward; under data parallelism in two halves so that the all-reduce of the upper blocks'
@@ -118,7 +127,7 @@ class GanEngine:
         """Enqueue one full step on the current stream (no host sync)."""
         L, B = _lib.lib(), self.B
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        nd, ng = self._nets()
+        (nd, nd_b, nd_c), ng = self._nets()
         fd, fg = self.vit._flat, self.gen._flat
         img_bytes = self.imgs[0].numel() * 2
         fake_ptr = C.c_void_p(self.imgs.data_ptr() + B * img_bytes)
@@ -137,18 +146,19 @@ class GanEngine:
                 src = C.c_void_p(self.imgs.data_ptr() + half * B * img_bytes)
                 lg = C.c_void_p(self.logits.data_ptr() + 4 * half * B * self.Kc)
                 dl = C.c_void_p(self.dlogits.data_ptr() + 4 * half * B * self.Kc)
-                _lib.check(L.vg_vit_forward(C.byref(nd), B, src, 1, _p(self.ws_d), lg, st), "vg_vit_forward")
+                net = nd if half == 0 else nd_b
+                _lib.check(L.vg_vit_forward(C.byref(net), B, src, 1, _p(self.ws_d), lg, st), "vg_vit_forward")
                 self._loss(half * B, B, role, role, st)
                 if half == 0:
-                    _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), dl, None, 1, st), "vg_vit_backward")
+                    _lib.check(L.vg_vit_backward(C.byref(net), B, _p(self.ws_d), dl, None, 1, st), "vg_vit_backward")
                 else:  # second pass finishes D.grad: exchange it as it completes
-                    self._d_backward(nd, B, dl, 1, None, st)
+                    self._d_backward(net, B, dl, 1, None, st)
         self.sync.wait()
         self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st)
         fg.grad.zero_()            # gan.generator.zero_grad(), training.py:199
-        _lib.check(L.vg_vit_forward(C.byref(nd), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
+        _lib.check(L.vg_vit_forward(C.byref(nd_c), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
         self._loss(0, B, 2, 2, st)
-        _lib.check(L.vg_vit_backward(C.byref(nd), B, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st), "vg_vit_backward")
+        _lib.check(L.vg_vit_backward(C.byref(nd_c), B, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st), "vg_vit_backward")
         _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
         self.sync.reduce_range(fg.grad, 0, fg.total)
         self.sync.wait()

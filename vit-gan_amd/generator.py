@@ -7,8 +7,9 @@ MLP), final SLN, two SIREN layers; output ``[B, C, IH, IW]`` is the flat view of
 Forward/backward are ONE C call each into the fused engine.
 
 Dropout: the reference block applies Dropout(0.2) to the attention output and inside the MLP
-(src/v1/config.py:36,39) in train mode; the fused pass treats them as identity (parity is defined
-in eval mode - RNG streams cannot match).
+(src/v1/config.py:36,39) in train mode; here both are fused into the GEMM epilogues (counter-based
+mask, p quantised to 1/256) and are active in ``train()`` mode, identity in ``eval()`` - parity with the
+reference is defined in eval mode, RNG streams cannot match.
 """
 from __future__ import annotations
 
@@ -50,14 +51,15 @@ def _sln_holder(E):
 
 class _GenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod: "SirenGenerator", z, anchor):
+    def forward(ctx, mod: "SirenGenerator", z, anchor, drop_p):
         fp = mod._flat
         fp.refresh_shadow()
+        ctx.drop = (float(drop_p), int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0)
         B = z.shape[0]
         zin = z.detach().float().contiguous()
         ws = torch.empty(mod._ws_bytes(B), dtype=torch.uint8, device=z.device)
         img = torch.empty(B, mod.channels, mod.image_size, mod.image_size, dtype=torch.bfloat16, device=z.device)
-        net = mod._net()
+        net = mod._net(ctx.drop)
         _lib.check(_lib.lib().vg_gen_forward(C.byref(net), B, zin.data_ptr(), ws.data_ptr(), img.data_ptr(),
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vg_gen_forward")
         ctx.mod, ctx.ws, ctx.B = mod, ws, B
@@ -68,19 +70,20 @@ class _GenFn(torch.autograd.Function):
         mod = ctx.mod
         mod._flat.attach_grads()
         d = dimg.detach().to(torch.bfloat16).contiguous()
-        net = mod._net()
+        net = mod._net(ctx.drop)
         _lib.check(_lib.lib().vg_gen_backward(C.byref(net), ctx.B, ctx.ws.data_ptr(), d.data_ptr(),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vg_gen_backward")
         ctx.ws = None
-        return None, None, None
+        return None, None, None, None
 
 
 class SirenGenerator(nn.Module):
     def __init__(self, latent=1024, image_size=32, channels=3, embed=384, heads=4, layers=4, siren_hidden=768,
-                 omega_0=30.0, out_dtype=torch.float32):
+                 omega_0=30.0, out_dtype=torch.float32, dropout=0.2):
         super().__init__()
         T, E, hd = image_size, embed, embed // heads
         self.latent, self.image_size, self.channels, self.out_dtype = latent, image_size, channels, out_dtype
+        self.dropout_p = float(dropout)  # attention_dropout_rate = mlp_dropout = 0.2 in src/v1/config.py:36,39
         self.mapping_mlp = _mlp_holder(T * E, latent)
         self.embedding = nn.Parameter(torch.randn(T, E))
         blocks = []
@@ -151,9 +154,9 @@ class SirenGenerator(nn.Module):
             raise RuntimeError("vg_gen_ws_bytes failed")
         return n
 
-    def _net(self):
+    def _net(self, drop=(0.0, 0)):
         fp = self._flat
-        return _lib.VgGenNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr())
+        return _lib.VgGenNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr(), float(drop[0]), int(drop[1]), None)
 
     def forward(self, z):
         if not z.is_cuda:
@@ -161,4 +164,4 @@ class SirenGenerator(nn.Module):
         if not self._flat.aliased():
             self._flat.named = dict(self.named_parameters())
             self._flat.rebuild()
-        return _GenFn.apply(self, z, self.embedding)
+        return _GenFn.apply(self, z, self.embedding, self.dropout_p if self.training else 0.0)

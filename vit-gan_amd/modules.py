@@ -152,18 +152,24 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _fresh_seed() -> int:
+    """Per-forward dropout seed drawn from torch's CPU generator (reproducible under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 class _VitFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod: "VisionTransformer", x, anchor):
+    def forward(ctx, mod: "VisionTransformer", x, anchor, drop_p):
         fp = mod._flat
         fp.refresh_shadow()
+        ctx.drop = (float(drop_p), _fresh_seed() if drop_p > 0 else 0)
         B = x.shape[0]
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         xin = x.detach().contiguous()
         ws = torch.empty(mod._ws_bytes(B), dtype=torch.uint8, device=x.device)
         logits = torch.empty(B, mod._dims.Kc, dtype=torch.float32, device=x.device)
-        net = mod._net(need_grad=False)
+        net = mod._net(need_grad=False, drop=ctx.drop)
         _lib.check(_lib.lib().vg_vit_forward(C.byref(net), B, xin.data_ptr(), int(xin.dtype == torch.bfloat16),
                                              ws.data_ptr(), logits.data_ptr(), _stream()), "vg_vit_forward")
         ctx.mod, ctx.ws, ctx.B, ctx.xdtype = mod, ws, B, x.dtype
@@ -179,18 +185,20 @@ class _VitFn(torch.autograd.Function):
             mod._flat.attach_grads()
         dl = dlogits.detach().float().contiguous()
         dimg = torch.empty(ctx.xshape, dtype=torch.bfloat16, device=dl.device) if ctx.need_dx else None
-        net = mod._net(need_grad=want_w)
+        net = mod._net(need_grad=want_w, drop=ctx.drop)
         _lib.check(_lib.lib().vg_vit_backward(C.byref(net), ctx.B, ctx.ws.data_ptr(), dl.data_ptr(),
                                               None if dimg is None else dimg.data_ptr(), int(want_w), _stream()),
                    "vg_vit_backward")
         ctx.ws = None
-        return None, (None if dimg is None else dimg.to(ctx.xdtype)), None
+        return None, (None if dimg is None else dimg.to(ctx.xdtype)), None, None
 
 
 class VisionTransformer(nn.Module):
     """src/v2/modules.py:202-238.  Parameters live in one flat buffer (flatparams.py); ``forward``
-    is one fused pass of the HIP engine unless dropout is active, in which case the blocks run
-    one by one through ops.py with torch's dropout between them (RNG parity is not defined)."""
+    is one fused pass of the HIP engine; in train mode with ``dropout > 0`` the three nn.Dropout sites of
+    the reference (:80,:170,:176) are applied inside the GEMM epilogues with a counter-based mask (RNG-stream
+    parity with torch is not defined; p is quantised to 1/256).  ``composed_forward`` runs the same network
+    block by block through ops.py with torch's own dropout."""
 
     def __init__(self, n_channels, embed_dim, n_layers, n_attention_heads, forward_mul, image_size, patch_size,
                  n_classes, dropout=0.1):
@@ -224,9 +232,10 @@ class VisionTransformer(nn.Module):
             raise RuntimeError("vg_vit_ws_bytes failed")
         return n
 
-    def _net(self, need_grad: bool) -> _lib.VgVitNet:
+    def _net(self, need_grad: bool, drop=(0.0, 0)) -> _lib.VgVitNet:
         fp = self._flat
-        return _lib.VgVitNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr() if need_grad else None)
+        return _lib.VgVitNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr() if need_grad else None,
+                             float(drop[0]), int(drop[1]), None)
 
     # -- forward -----------------------------------------------------------------------------
     def forward(self, x):
@@ -235,14 +244,17 @@ class VisionTransformer(nn.Module):
         if not self._flat.aliased():
             self._flat.named = dict(self.named_parameters())
             self._flat.rebuild()
-        if self.training and self._dropout_p > 0.0:
-            h = self.embedding(x)
-            for block in self.encoder:
-                h = block(h)
-            # the classifier reads the CLS row only (:195), so normalising that row is equivalent to :236
-            h = ops.layer_norm(h[:, :1, :], self.norm.weight, self.norm.bias, self.norm.eps)
-            return self.classifier(h)
-        return _VitFn.apply(self, x, self.norm.weight)
+        p = self._dropout_p if self.training else 0.0
+        return _VitFn.apply(self, x, self.norm.weight, p)
+
+    def composed_forward(self, x):
+        """The same network through the per-operator HIP path (ops.py) and torch's nn.Dropout modules."""
+        h = self.embedding(x)
+        for block in self.encoder:
+            h = block(h)
+        # the classifier reads the CLS row only (:195), so normalising that row is equivalent to :236
+        h = ops.layer_norm(h[:, :1, :], self.norm.weight, self.norm.bias, self.norm.eps)
+        return self.classifier(h)
 
 
 # --------------------------------------------------------------------------------------------
