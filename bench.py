@@ -47,22 +47,22 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def gemm_roofline(torch, B):
-    """Dominant kernel = vg_gemm_kernel<NT> at the QKV-projection shape of the fused real+fake pass
-    (M = 2B*65, N = 1152, K = 384).  Average launch duration measured live with HIP events on the
-    stream the kernel runs on; algorithmic FLOPs = 2*M*N*K."""
+    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<NN,4,...>,
+    the input-gradient GEMM; timed at its heaviest shape, the QKV dgrad of the fused real+fake pass:
+    dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.  Average launch duration is measured live with HIP
+    events on the stream the kernel runs on; achieved = algorithmic FLOPs (2*M*N*K) / that duration.
+    `traffic` = HBM bytes per launch of this kernel from the PMC passes stored under profiles/."""
     import ctypes as C
     from vit_gan_amd import _lib
-    M, N, K = 2 * B * 65, 1152, 384
-    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    M, N, K = 2 * B * 65, 1152, 384  # dY [M,N], W [N,K], dX [M,K]
+    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
-    bias = torch.zeros(N, device="cuda")
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = _lib.lib()
 
     def run():
-        _lib.check(L.vg_linear_fwd(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), None, None, M, N, K, 0, 0.0, st),
-                   "vg_linear_fwd")
+        _lib.check(L.vg_linear_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, N, K, 0, None, None, 0.0, st), "vg_linear_dgrad")
     for _ in range(5):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,8 +74,18 @@ def gemm_roofline(torch, B):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")) as f:
+            rec = json.load(f)["kernels"]["NN qkv dgrad"]
+        if rec["out_rows_cols_reduction"] == [M, K, N]:
+            traffic = rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "traffic": None, "kernel": "vg_gemm_kernel<NT> QKV projection", "shape": [M, N, K], "avg_launch_us": round(ms * 1e3, 2)}
+            "traffic": traffic, "kernel": "vg_gemm_kernel<NN, 256x128 tile> (QKV input gradient)", "shape_M_N_K": [M, K, N],
+            "algorithmic_flops_per_launch": 2.0 * M * N * K, "algorithmic_bytes_per_launch": 2 * (M * N + N * K + M * K),
+            "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def main():

@@ -115,6 +115,11 @@ int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream
  * Whole-network passes (what the nn.Modules call: one C call per forward / backward)
  * ---------------------------------------------------------------------------------------- */
 
+/* Execution context (second HIP stream + events) for concurrent weight-gradient work; host only.  One per
+ * engine / process; the calls using it must come from one host thread. */
+int vg_ctx_create(void** out_ctx);
+int vg_ctx_destroy(void* ctx);
+
 /* v2 VisionTransformer (src/v2/modules.py:202-238) = ViTDiscriminator.forward (:393-395). */
 typedef struct VgVitDims {
   int C, IH, P, E, H, L, R, Kc; /* channels, image size, patch, embed, heads, layers, mlp ratio, classes */
@@ -144,6 +149,8 @@ typedef struct VgVitNet {
   float dropout_p;
   unsigned long long dropout_seed;
   const unsigned* dropout_step; /* optional device counter mixed into the mask key (hipGraph replay); NULL = none */
+  void* ctx;                    /* optional vg_ctx_create() handle: the backward runs its weight-gradient side on the
+                                   context's second stream, concurrently with the input-gradient chain; NULL = one stream */
 } VgVitNet;
 /* img: [B,C,IH,IH] fp32 (img_is_bf16 = 0) or bf16; logits fp32 [B,Kc].  ws keeps everything the
  * backward needs; one ws per in-flight forward. */

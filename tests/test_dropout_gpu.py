@@ -61,7 +61,7 @@ def test_vit_train_mode_matches_oracle_with_same_masks():
     lay, slots = flat.vit_layout(dd), flat.vit_slots(dd)
     P = flat.pack(slots, lay.total, st_np, device="cuda")
     Pb, G = P.to(torch.bfloat16), torch.zeros_like(P)
-    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), p, seed, None)
+    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), p, seed, None, _lib.context())
     ws = torch.empty(_lib.lib().vg_vit_ws_bytes(C.byref(dd), B), dtype=torch.uint8, device="cuda")
     logits = torch.empty(B, 1, device="cuda")
     X, Rd = x.cuda(), R.cuda()
@@ -78,7 +78,7 @@ def test_vit_train_mode_matches_oracle_with_same_masks():
         u.assert_close(grads[k], prm.grad, 2.0 ** -4, f"grad {k} (train mode)")
     # staged backward == one-shot backward, bit for bit
     G2 = torch.zeros_like(P)
-    net2 = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G2.data_ptr(), p, seed, None)
+    net2 = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G2.data_ptr(), p, seed, None, None)
     u.call("vg_vit_forward", C.byref(net2), B, u.ptr(X), 0, u.ptr(ws), u.ptr(logits), u.stream())
     for a, b in ((0, 3), (3, 5), (5, d.layers + 2)):
         u.call("vg_vit_backward_stages", C.byref(net2), B, u.ptr(ws), u.ptr(Rd), u.ptr(dimg), 1, a, b, u.stream())

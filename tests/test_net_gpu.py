@@ -51,7 +51,7 @@ def test_vit_forward_backward_vs_oracle(name, batch):
     P = flat.pack(slots, lay.total, st_np, device="cuda")
     Pb = P.to(torch.bfloat16)
     G = torch.zeros_like(P)
-    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr())
+    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), 0.0, 0, None, None)
     ws = torch.empty(_lib.lib().vg_vit_ws_bytes(C.byref(dd), B), dtype=torch.uint8, device="cuda")
     logits = torch.empty(B, d.classes, device="cuda")
     X = x.cuda()
@@ -106,7 +106,7 @@ def test_gen_forward_backward_vs_oracle(name):
     P = flat.pack(slots, lay.total, st_np, device="cuda")
     Pb = P.to(torch.bfloat16)
     G = torch.zeros_like(P)
-    net = _lib.VgGenNet(gd, P.data_ptr(), Pb.data_ptr(), G.data_ptr())
+    net = _lib.VgGenNet(gd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), 0.0, 0, None)
     ws = torch.empty(_lib.lib().vg_gen_ws_bytes(C.byref(gd), B), dtype=torch.uint8, device="cuda")
     img = torch.empty(B, d.channels, d.image, d.image, dtype=torch.bfloat16, device="cuda")
     Zd = z.cuda()

@@ -29,7 +29,7 @@ class VgVitLayout(C.Structure):
 
 class VgVitNet(C.Structure):
     _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
-                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p)]
+                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("ctx", c_void_p)]
 
 
 class VgGenDims(C.Structure):
@@ -68,6 +68,8 @@ _SIGNATURES = {
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "vg_cast_f32_bf16": (c_int, [P, P, c_ll, P]),
+    "vg_ctx_create": (c_int, [C.POINTER(c_void_p)]),
+    "vg_ctx_destroy": (c_int, [c_void_p]),
     "vg_vit_layout": (c_int, [C.POINTER(VgVitDims), C.POINTER(VgVitLayout)]),
     "vg_vit_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
     "vg_vit_forward": (c_int, [C.POINTER(VgVitNet), c_int, P, c_int, P, P, P]),
@@ -112,6 +114,19 @@ def lib() -> C.CDLL:
             raise RuntimeError("libvitgan_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib
+
+
+_ctx = None
+
+
+def context() -> c_void_p:
+    """Process-wide execution context (second stream + events) for concurrent weight-gradient work."""
+    global _ctx
+    if _ctx is None:
+        h = c_void_p()
+        check(lib().vg_ctx_create(C.byref(h)), "vg_ctx_create")
+        _ctx = h
+    return _ctx
 
 
 class HipError(RuntimeError):

@@ -13,6 +13,35 @@
 
 static inline long long al64(long long x) { return (x + 63) & ~63LL; }
 
+// Optional execution context: a second stream + events so that the weight-gradient side of a backward
+// (wgrad GEMMs, bias / LayerNorm-affine reductions - everything that only writes the gradient buffer) runs
+// concurrently with the input-gradient chain of the next block and fills the CUs its short tails leave idle.
+#define VG_CTX_EVENTS 72
+struct VgCtx {
+  hipStream_t side;
+  hipEvent_t ev_main[VG_CTX_EVENTS], ev_side[VG_CTX_EVENTS];
+};
+extern "C" int vg_ctx_create(void** out) {
+  if (!out) return -1;
+  VgCtx* c = new VgCtx();
+  hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  for (int i = 0; i < VG_CTX_EVENTS; ++i) {
+    if ((e = hipEventCreateWithFlags(&c->ev_main[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+extern "C" int vg_ctx_destroy(void* ctx) {
+  if (!ctx) return 0;
+  VgCtx* c = (VgCtx*)ctx;
+  for (int i = 0; i < VG_CTX_EVENTS; ++i) { (void)hipEventDestroy(c->ev_main[i]); (void)hipEventDestroy(c->ev_side[i]); }
+  (void)hipStreamDestroy(c->side);
+  delete c;
+  return 0;
+}
+
 // =============================================================================================
 //                                       layouts
 // =============================================================================================
@@ -163,7 +192,10 @@ static inline long long tiles128(long long m, long long n) { return ((m + 127) /
 struct VitWs {
   bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *z1, *a1, *xcls, *hcls, *th;
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf;
-  bf16 *g[3], *gm[2], *dz1, *dxn, *dao, *dqkv, *gp, *dA, *dzh, *dhcls, *dxcls;
+  // backward scratch, one set per block parity (block l uses set l&1; its LN1 backward writes gin/gm2 of set (l-1)&1):
+  // the weight-gradient side of block l still reads set l&1 while the main stream works on block l-1 in the other set
+  struct Set { bf16 *gin, *gm2, *gmid, *gm1, *dz1, *dqkv; float *part1, *part2; } set[2];
+  bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *tok_sum, *slab;
 };
 static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
@@ -185,12 +217,17 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   w.mean1 = c.take<float>(L * M); w.rstd1 = c.take<float>(L * M);
   w.mean2 = c.take<float>(L * M); w.rstd2 = c.take<float>(L * M);
   w.meanf = c.take<float>(B); w.rstdf = c.take<float>(B);
-  for (int i = 0; i < 3; ++i) w.g[i] = c.take<bf16>(M * E);
-  for (int i = 0; i < 2; ++i) w.gm[i] = c.take<bf16>(M * E);  // dropout-masked copies of residual-stream gradients
-  w.dz1 = c.take<bf16>(M * rE);
+  for (int i = 0; i < 2; ++i) {
+    VitWs::Set& t = w.set[i];
+    t.gin = c.take<bf16>(M * E); t.gm2 = c.take<bf16>(M * E);   // dL/dX entering the block, and its dropout-masked copy
+    t.gmid = c.take<bf16>(M * E); t.gm1 = c.take<bf16>(M * E);  // same after the MLP half of the block
+    t.dz1 = c.take<bf16>(M * rE);
+    t.dqkv = c.take<bf16>(M * 3 * E);
+    t.part1 = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
+    t.part2 = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
+  }
   w.dxn = c.take<bf16>(M * E);
   w.dao = c.take<bf16>(M * E);
-  w.dqkv = c.take<bf16>(M * 3 * E);
   w.gp = c.take<bf16>(B * NP * E);
   w.dA = c.take<bf16>(B * NP * Kp);
   w.dzh = c.take<bf16>(B * E); w.dhcls = c.take<bf16>(B * E); w.dxcls = c.take<bf16>(B * E);
@@ -284,15 +321,9 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   const int lnparts = vg_ln_bwd_nparts(M);
   const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
   const bool drop = dr.thr != 0;
-  // with dropout, the gradient entering a dropped branch is the residual-stream gradient times the mask:
-  // gm2 (MLP branch, masked g) and gm1 (attention branch, masked gmid) are second outputs of the LN backward
-  bf16* const gm2buf = w.gm[0];
-  bf16* const gm1buf = w.gm[1];
-
-  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
-  const int layers_done = stage_begin > 0 ? stage_begin - 1 : 0;  // blocks already processed by earlier calls
-  if (layers_done & 1) { bf16* t = g; g = gin; gin = t; }          // g and gin swap once per block
-  bool have_g_colsum = layers_done > 0;  // part[:, 2E:3E] holds colsum(g) when g came out of an LN backward
+  VgCtx* ctx = (VgCtx*)net->ctx;
+  hipStream_t sd = ctx ? ctx->side : st;  // stream of the weight-gradient side work
+  const int top = d.L - 1;
   if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
   VG_TRY(vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr,
@@ -307,10 +338,11 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st));
   if (want_wgrad)
     VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
-  VG_TRY(vg_scatter_cls_launch(w.dxcls, g, B, S, E, st));
-  if (drop) VG_TRY(vg_dropout_apply_launch(g, gm2buf, (long long)M * E, dr.thr, site_key(dr, 2 + 2 * (d.L - 1)), dr.scale, dr.step, st));
+  VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st));
+  if (drop) VG_TRY(vg_dropout_apply_launch(w.set[top & 1].gin, w.set[top & 1].gm2, (long long)M * E, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step, st));
   }
 
+  int last_side = -1;  // highest-index side event recorded by this call (for the join)
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage < stage_begin) continue;
@@ -324,49 +356,62 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* xn2 = w.xn2 + (size_t)l * ME;
     const bf16* z1 = w.z1 + (size_t)l * M * rE;
     const bf16* a1 = w.a1 + (size_t)l * M * rE;
-    const bf16* gb2 = drop ? gm2buf : g;  // gradient w.r.t. the fc2 output (before dropout2)
-    // fc2 bias grad = colsum(gb2)
-    if (want_wgrad && !have_g_colsum) VG_TRY(vg_colsum_bf16_launch(gb2, E, M, E, w.part_cs, G + lo + lay.b2, 1, st));
+    VitWs::Set& cur = w.set[l & 1];
+    VitWs::Set& nxt = w.set[(l & 1) ^ 1];  // receives dL/dX[l] for block l-1
+    const bf16* g = cur.gin;
+    const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
+    // ---------------- input-gradient chain (main stream) ----------------
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
-    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, w.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
-    if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dz1, rE, M, rE, w.part_cs, G + lo + lay.b1, 1, st));
-    VG_TRY(lin_dgrad(w.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, gmid, w.part, M, E,
-                            drop ? gm1buf : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
-    const bf16* gb1 = drop ? gm1buf : gmid;  // gradient w.r.t. the out-projection output (before dropout1)
-    if (want_wgrad)
-      VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0, 1, st));
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
+    VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, cur.part2, M, E,
+                            drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, w.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
-    if (want_wgrad) VG_TRY(vg_colsum_bf16_launch(w.dqkv, 3 * E, M, 3 * E, w.part_cs, G + lo + lay.bqkv, 1, st));
-    VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
-    if (want_wgrad) {
-      // the four weight gradients of the block as ONE grouped split-K launch (needs g, gmid: before g is recycled)
+    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    // LN1 backward writes dL/dX[l] (and its masked copy for the dropout it meets next) into the OTHER set, which the
+    // weight-gradient side of block l+1 may still be reading: wait for it first
+    if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
+      VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[l + 1], 0));
+    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, cur.part1, M, E,
+                            drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+    if (!want_wgrad) continue;
+    // ---------------- weight-gradient side (second stream when a context is given) ----------------
+    if (ctx) {
+      VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
+      VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
+    }
+    if (l == top) VG_TRY(vg_colsum_bf16_launch(gb2, E, M, E, w.part_cs, G + lo + lay.b2, 1, sd));  // lower blocks: from LN1's partials
+    VG_TRY(vg_colsum_bf16_launch(cur.dz1, rE, M, rE, w.part_cs, G + lo + lay.b1, 1, sd));
+    VG_TRY(vg_colsum_f32_launch(cur.part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0, 1, sd));
+    VG_TRY(vg_colsum_bf16_launch(cur.dqkv, 3 * E, M, 3 * E, w.part_cs, G + lo + lay.bqkv, 1, sd));
+    {
+      // the four weight gradients of the block as ONE grouped split-K launch
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
       const int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
       VgGemmProb pr[4];
-      pr[0] = wg(w.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
+      pr[0] = wg(cur.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
-      pr[2] = wg(w.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
+      pr[2] = wg(cur.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
       pr[3] = wg(gb2, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
-      VG_TRY(vg_gemm_launch(pr, 4, VG_TN, st));
-      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+      VG_TRY(vg_gemm_launch(pr, 4, VG_TN, sd));
+      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, sd));
     }
-    // second output: the same gradient masked for the dropout it meets next (block l-1's MLP branch, or the
-    // embedding dropout below block 0); the wgrad launch above has consumed gm2buf, so it can be rewritten
-    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gin, w.part, M, E,
-                            drop ? gm2buf : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
-    if (want_wgrad) {
+    {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
-      VG_TRY(vg_colsum_f32_launch(w.part, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0, 1, st));
+      VG_TRY(vg_colsum_f32_launch(cur.part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0, 1, sd));
     }
-    have_g_colsum = true;
-    bf16* t = g; g = gin; gin = t;  // g now = dL/dX[l]
+    if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_side[l], sd)); last_side = l; }
   }
+  // join: everything this call put on the side stream is ordered before whatever follows on the main stream
+  if (ctx && last_side >= 0) VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[last_side], 0));
+  bf16* g = w.set[1].gin;  // dL/dX[0]: block 0 (set 0) wrote it into the other set
+  const bf16* g0m = w.set[1].gm2;
 
   if (stage_end < d.L + 2) return 0;
   // ---- patch embedding ----
-  if (drop) g = gm2buf;  // dL/dX[0] masked by the embedding dropout (second output of block 0's LN1 backward)
+  if (drop) g = (bf16*)g0m;  // dL/dX[0] masked by the embedding dropout (second output of block 0's LN1 backward)
   if (want_wgrad) {
     VG_TRY(vg_batch_sum_launch(g, w.tok_sum, B, S, E, st));
     VG_TRY(vg_embed_small_grads_launch(w.tok_sum, G + lay.cls, G + lay.pos, G + lay.conv_b, S, E, st));

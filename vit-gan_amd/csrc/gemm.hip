@@ -479,7 +479,8 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     if (act == VG_ACT_NONE) {
       if (feat == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, 0);
       else if (feat == F_RES) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RES);
-      else if (feat & F_DROP) VG_BY_WM(VG_NT, VG_ACT_NONE, F_DROP | F_RES | F_RESF | F_REMAP);  // training-mode dropout sites
+      else if (feat == (F_DROP | F_RES)) VG_BY_WM(VG_NT, VG_ACT_NONE, F_DROP | F_RES);        // x + drop(Linear(.)): block sites
+      else if (feat & F_DROP) VG_BY_WM(VG_NT, VG_ACT_NONE, F_DROP | F_RES | F_RESF | F_REMAP);  // embedding / generator block 0
       else if ((feat & ~(F_RESF | F_REMAP)) == 0) VG_BY_WM(VG_NT, VG_ACT_NONE, F_RESF | F_REMAP);
       else VG_BY_WM(VG_NT, VG_ACT_NONE, F_ALL);
     } else if (feat & F_DROP) {

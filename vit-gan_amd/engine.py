@@ -38,6 +38,7 @@ class GanEngine:
                  lr_d: float = 5e-4, lr_g: float = 5e-4, weight_decay: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
+                 concurrent_wgrad: bool = True,
                  process_group: Optional["dist.ProcessGroup"] = None):
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
@@ -79,6 +80,7 @@ class GanEngine:
         self.m_g, self.v_g = torch.zeros_like(fg.flat), torch.zeros_like(fg.flat)
         fd.refresh_shadow()
         fg.refresh_shadow()
+        self.ctx = _lib.context() if concurrent_wgrad else None
         self.steps = 0
         self._graph = None
         self._use_graph = bool(use_graph)
@@ -91,7 +93,7 @@ class GanEngine:
         # still draws fresh masks; pass A = [real;fake] (or real), B = fake, C = generator pass through D
         step_ptr = self.step_t.data_ptr()
         mk = lambda i: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(),  # noqa: E731
-                                     self.p_d, self.seed * 8 + i, step_ptr)
+                                     self.p_d, self.seed * 8 + i, step_ptr, self.ctx)
         ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr)
         return (mk(0), mk(1), mk(2)), ng
 

@@ -235,7 +235,7 @@ class VisionTransformer(nn.Module):
     def _net(self, need_grad: bool, drop=(0.0, 0)) -> _lib.VgVitNet:
         fp = self._flat
         return _lib.VgVitNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr() if need_grad else None,
-                             float(drop[0]), int(drop[1]), None)
+                             float(drop[0]), int(drop[1]), None, _lib.context() if need_grad else None)
 
     # -- forward -----------------------------------------------------------------------------
     def forward(self, x):
