@@ -130,7 +130,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
   constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);
-  constexpr int SMEM_BYTES = (NSTAGE * STAGE_BYTES > NW * 32 * 272) ? NSTAGE * STAGE_BYTES : NW * 32 * 272;  // ring, reused by the epilogue
+  constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   // XCD-aware block order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
@@ -265,32 +265,39 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
   // every store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt
   // retires in order, so a load issued behind stores would wait for them.
   STAMP(4);
-  __syncthreads();  // every wave is done reading the operand ring
+  // ---- epilogue: registers only ---------------------------------------------------------------
+  // A lane holds, per (n-tile, m-tile), 4 consecutive n of row li.  v_permlane16_swap between the even and the
+  // odd n-tile of a pair hands every lane 8 CONSECUTIVE n of one tile (even lane-groups keep the even tile,
+  // odd lane-groups the odd one), so each lane loads/stores 16 B (bf16) or 32 B (fp32) per slot with no trip
+  // through LDS (the LDS transpose of the first version cost ~1.5k LDS cycles per workgroup and stalled the
+  // co-resident workgroup's main loop).  8 slots per lane: q = 2*mt + pair.
   STAMP(5);
-  unsigned char* creg = smem + wid * (32 * 272);
-  const int er = lane >> 3, ec = lane & 7;  // read-back: 8 rows x 8 column-chunks per pass
-  const int n = n0 + wn * 64 + ec * 8;
-  const bool ncol_ok = n < eN;
-  const int mrow0 = m0 + wm * 64 + er;  // slot q (= 4*half + it) covers tile row mrow0 + 8*q
   constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD);
   constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
   constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
   constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0, HAS_DROP = (FEAT & F_DROP) != 0;
   constexpr bool PRE_BF = NEED_ZBF || HAS_RES, PRE_F = NEED_ZF || HAS_RESF;
-  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-  bf16x8 pre_bf[PRE_BF ? 8 : 1];
-  f32x4 pre_f0[PRE_F ? 8 : 1], pre_f1[PRE_F ? 8 : 1];
+  const int mrow0 = m0 + wm * 64 + li;                               // slot (mt, .) covers row mrow0 + 16*mt
+  const int ncol0 = n0 + wn * 64 + ((g & 1) << 4) + ((g & 2) << 2);  // slot (., pair) covers columns ncol0 + 32*pair .. +7
   auto out_row = [&](int m) -> int {
     if (HAS_REMAP && rip > 0) return (m / rip) * rop + roo + (m % rip);
     return m;
   };
+  f32x4 b0[2], b1[2];
+  bf16x8 pre_bf[PRE_BF ? 8 : 1];
+  f32x4 pre_f0[PRE_F ? 8 : 1], pre_f1[PRE_F ? 8 : 1];
   if (MODE != VG_TN) {
-    if (ebias && ncol_ok) { b0 = *(const f32x4*)(ebias + n); b1 = *(const f32x4*)(ebias + n + 4); }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int n = ncol0 + 32 * pr;
+      b0[pr] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[pr] = b0[pr];
+      if (ebias && n < eN) { b0[pr] = *(const f32x4*)(ebias + n); b1[pr] = *(const f32x4*)(ebias + n + 4); }
+    }
     if (PRE_BF || PRE_F) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int m = mrow0 + 8 * q;
-        const bool ok = ncol_ok && m < eM;
+        const int m = mrow0 + 16 * (q >> 1), n = ncol0 + 32 * (q & 1);
+        const bool ok = n < eN && m < eM;
         if (PRE_BF) {
           bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
           if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
@@ -307,30 +314,21 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
     }
   }
   STAMP(6);
-  // phase 1: all LDS traffic (the compiler fences every ds_read behind vmcnt(0) once LDS-DMA has been
-  // used, so no global store may be in flight yet); phase 2: arithmetic + global stores.
-  f32x4 tlo[8], thi[8];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
-      const int mt = 2 * half + mh;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *(f32x4*)(creg + (mh * 16 + li) * 272 + (nt * 16 + 4 * g) * 4) = acc[nt][mt];
-    }
-    // same wave reads back what it wrote: LDS ops of one wave complete in order
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const unsigned char* rp = creg + (it * 8 + er) * 272 + ec * 32;
-      tlo[4 * half + it] = *(const f32x4*)rp;
-      thi[4 * half + it] = *(const f32x4*)(rp + 16);
-    }
-  }
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     {
-      const int m = mrow0 + 8 * q;
-      const f32x4 lo = tlo[q], hi = thi[q];
+      const int mt = q >> 1, pr = q & 1;
+      const int m = mrow0 + 16 * mt, n = ncol0 + 32 * pr;
+      const f32x4 te = acc[2 * pr][mt], to = acc[2 * pr + 1][mt];
+      f32x4 lo, hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // rows 1,3 of the even tile's register <-> rows 0,2 of the odd tile's
+        const unsigned ue = __float_as_uint(te[r]), uo = __float_as_uint(to[r]);
+        const auto sw = __builtin_amdgcn_permlane16_swap(ue, uo, false, false);
+        lo[r] = __uint_as_float(sw[0]);
+        hi[r] = __uint_as_float(sw[1]);
+      }
+      const bool ncol_ok = n < eN;
       if (m >= eM || !ncol_ok) continue;
       if (MODE == VG_TN) {
         float* dst = eCf + (size_t)split * ecfs + (unsigned)(m * eldcf + n);
@@ -338,8 +336,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
         *(f32x4*)(dst + 4) = hi;
         continue;
       }
-      float v[8] = {lo[0] + b0[0], lo[1] + b0[1], lo[2] + b0[2], lo[3] + b0[3],
-                    hi[0] + b1[0], hi[1] + b1[1], hi[2] + b1[2], hi[3] + b1[3]};
+      float v[8] = {lo[0] + b0[pr][0], lo[1] + b0[pr][1], lo[2] + b0[pr][2], lo[3] + b0[pr][3],
+                    hi[0] + b1[pr][0], hi[1] + b1[pr][1], hi[2] + b1[pr][2], hi[3] + b1[pr][3]};
       const int mo = out_row(m);
       if (HAS_PREF32 && epre) {
         float* dst = eCf + (unsigned)(mo * eldcf + n);
