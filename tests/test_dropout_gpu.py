@@ -69,7 +69,8 @@ def test_vit_train_mode_matches_oracle_with_same_masks():
     dimg = torch.empty(B, 3, 32, 32, dtype=torch.bfloat16, device="cuda")
     u.call("vg_vit_backward", C.byref(net), B, u.ptr(ws), u.ptr(Rd), u.ptr(dimg), 1, u.stream())
     u.sync()
-    u.assert_close(logits, out, 2.0 ** -5, "logits (train mode)")
+    # 13 dropout sites scale surviving activations by 256/230: bf16 rounding noise grows accordingly (2^-4 here, 2^-5 in eval)
+    u.assert_close(logits, out, 2.0 ** -4, "logits (train mode)")
     u.assert_close(dimg, xr.grad, 2.0 ** -4, "d_img (train mode)")
     grads = flat.unpack(slots, G)
     for k, prm in st.items():

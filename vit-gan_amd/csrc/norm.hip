@@ -1,116 +1,92 @@
 // LayerNorm / self-modulated LayerNorm (SLN) forward + backward and the small deterministic
-// reductions that go with them.  gfx950, wave64: one wave per row, E/64 elements per lane.
+// reductions that go with them.  gfx950, wave64: 16 lanes per row, 4 rows per wave, 16-byte accesses.
 //
 // Backward kernels never use float atomics: every workgroup writes one row of partial column
 // sums ([n_wg][part_width] fp32) and vg_colsum_f32 folds them in a fixed order, so results are
 // bitwise reproducible run to run.
 #include "vg_common.h"
 
-#define LN_MAX_PER_LANE 16  // E <= 1024
 #define LN_MAX_PARTS 512    // partial rows written by the backward kernels (fixed upper bound)
 
-// ------------------------------------------------------------------------------------------
-// y = LN(x) * gamma + beta ; stats saved for backward.  Row r of x at x + r*xs (elements).
-__global__ __launch_bounds__(256) void vg_ln_fwd_kernel(const bf16* __restrict__ x, long long xs,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        bf16* __restrict__ y, long long ys, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, int R, int E, float eps) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= R) return;
-  const int npl = E >> 7;  // bf16x2 per lane
-  const bf16x2* xr = (const bf16x2*)(x + (size_t)row * xs);
-  float v[LN_MAX_PER_LANE];
-  float s = 0.f;
+// Thread layout of every kernel below: a wave handles 4 rows at a time, 16 lanes per row; lane `sub` of a
+// row owns the 16-byte chunks sub, sub+16, ... (NV = E/128 chunks of 8 bf16), so each wave-instruction
+// moves 4 x 256 contiguous bytes with 16 B per lane (cdna_hip_programming.md Guideline 13).
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a row group
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+  return v;
+}
+__device__ __forceinline__ void unpack8(const bf16x8 t, float (&o)[8]) {
 #pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const bf16x2 t = xr[lane + 64 * i];
-      v[2 * i] = vg_bf2f(t[0]); v[2 * i + 1] = vg_bf2f(t[1]);
-      s += v[2 * i] + v[2 * i + 1];
-    }
-  const float mu = vg_wave_sum(s) / (float)E;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const float a = v[2 * i] - mu, c = v[2 * i + 1] - mu;
-      q += a * a + c * c;
-    }
-  const float rs = rsqrtf(vg_wave_sum(q) / (float)E + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-  bf16x2* yr = (bf16x2*)(y + (size_t)row * ys);
-#pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const int c = 2 * (lane + 64 * i);
-      bf16x2 o;
-      o[0] = vg_f2bf((v[2 * i] - mu) * rs * gamma[c] + beta[c]);
-      o[1] = vg_f2bf((v[2 * i + 1] - mu) * rs * gamma[c + 1] + beta[c + 1]);
-      yr[lane + 64 * i] = o;
-    }
+  for (int j = 0; j < 8; ++j) o[j] = vg_bf2f(t[j]);
 }
 
 // ------------------------------------------------------------------------------------------
-// SLN forward (src/v1/spectral_layer_norm.py:19-20): out = w * (gs * (LN(h)*lw + lb) + bs)
-// gs / bs are device scalars.  h_bcast_rows > 0: h has only that many rows (the generator's
-// learned embedding [T,E], broadcast over the batch): row r reads h row r % h_bcast_rows.
-__global__ __launch_bounds__(256) void vg_sln_fwd_kernel(const bf16* __restrict__ h, int h_bcast_rows,
-                                                         const bf16* __restrict__ wmod, const float* __restrict__ lw,
-                                                         const float* __restrict__ lb, const float* __restrict__ gs,
-                                                         const float* __restrict__ bs, bf16* __restrict__ y,
-                                                         float* __restrict__ mean, float* __restrict__ rstd, int R, int E,
-                                                         float eps) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= R) return;
-  const int npl = E >> 7;
-  const int hrow = h_bcast_rows > 0 ? row % h_bcast_rows : row;
-  const bf16x2* xr = (const bf16x2*)(h + (size_t)hrow * E);
-  const bf16x2* wr = (const bf16x2*)(wmod + (size_t)row * E);
-  float v[LN_MAX_PER_LANE];
+// LN forward:   y = LN(x) * gamma + beta                    (SLN = false; row r of x at x + r*xs)
+// SLN forward:  y = w * (gs * (LN(h) * lw + lb) + bs)       (src/v1/spectral_layer_norm.py:19-20; gs/bs device
+//               scalars; bcast_rows > 0: h has that many rows, broadcast over the batch)
+template <bool SLN, int NV>
+__global__ __launch_bounds__(256) void vg_ln_fwd_kernel(const bf16* __restrict__ x, long long xs, int bcast_rows,
+                                                        const bf16* __restrict__ wmod, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ gs,
+                                                        const float* __restrict__ bs, bf16* __restrict__ y, long long ys,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int R, float eps) {
+  constexpr int E = NV * 128;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane & 15;
+  const int row = (blockIdx.x * 4 + wv) * 4 + (lane >> 4);
+  const bool ok = row < R;
+  const int xrow = ok ? (bcast_rows > 0 ? row % bcast_rows : row) : 0;
+  const bf16* xr = x + (size_t)xrow * xs;
+  float v[NV][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const bf16x2 t = xr[lane + 64 * i];
-      v[2 * i] = vg_bf2f(t[0]); v[2 * i + 1] = vg_bf2f(t[1]);
-      s += v[2 * i] + v[2 * i + 1];
-    }
-  const float mu = vg_wave_sum(s) / (float)E;
+  for (int i = 0; i < NV; ++i) {
+    bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) t = *(const bf16x8*)(xr + 8 * (sub + 16 * i));
+    unpack8(t, v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[i][j];
+  }
+  const float mu = row16_sum(s) * (1.0f / E);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const float a = v[2 * i] - mu, c = v[2 * i + 1] - mu;
-      q += a * a + c * c;
-    }
-  const float rs = rsqrtf(vg_wave_sum(q) / (float)E + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-  const float g_s = gs[0], b_s = bs[0];
-  bf16x2* yr = (bf16x2*)(y + (size_t)row * E);
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-  for (int i = 0; i < LN_MAX_PER_LANE / 2; ++i)
-    if (i < npl) {
-      const int c = 2 * (lane + 64 * i);
-      const bf16x2 wm = wr[lane + 64 * i];
-      bf16x2 o;
-      o[0] = vg_f2bf(vg_bf2f(wm[0]) * (g_s * ((v[2 * i] - mu) * rs * lw[c] + lb[c]) + b_s));
-      o[1] = vg_f2bf(vg_bf2f(wm[1]) * (g_s * ((v[2 * i + 1] - mu) * rs * lw[c + 1] + lb[c + 1]) + b_s));
-      yr[lane + 64 * i] = o;
+    for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mu; q += c * c; }
+  const float rs = rsqrtf(row16_sum(q) * (1.0f / E) + eps);
+  if (!ok) return;
+  if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 8 * (sub + 16 * i);
+    const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+    float wm[8];
+    if (SLN) unpack8(*(const bf16x8*)(wmod + (size_t)row * E + c), wm);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gg = j < 4 ? g0[j] : g1[j - 4], bb = j < 4 ? b0[j] : b1[j - 4];
+      float r = (v[i][j] - mu) * rs * gg + bb;
+      if (SLN) r = wm[j] * (g_s * r + b_s);
+      o[j] = vg_f2bf(r);
     }
+    *(bf16x8*)(y + (size_t)row * ys + c) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
-// LN / SLN backward.  One workgroup = LN_ROWS_PER_WG rows; per-lane column accumulators are
-// folded across the 4 waves through LDS and written as ONE partial row:
+// LN / SLN backward.  Rows are dealt to (workgroup, wave, row-group) slots round-robin (fixed assignment ->
+// deterministic partial sums); per-lane column accumulators are folded across the 4 row groups of a wave by
+// shuffles and across the 4 waves through LDS, and written as ONE partial row per workgroup:
 //   part[wg][0:E]      = sum_rows dy_eff * xhat        (d gamma / d lw)
 //   part[wg][E:2E]     = sum_rows dy_eff               (d beta  / d lb)
-//   part[wg][2E:3E]    = sum_rows dx_out               (bias grad of the Linear feeding the residual)
+//   part[wg][2E:3E]    = sum_rows dx_out (masked copy when dxm != null: bias grad of the Linear feeding the branch)
 //   part[wg][3E], [3E+1] = SLN scalars d gs, d bs      (SLN only; width 3E+64)
-// dx_out = (gres ? gres : 0) + LN-backward(dy_eff).
+// dx = (gres ? gres : 0) + LN-backward(dy_eff);  dxm = dx * dropout mask (optional second output).
 // SLN: dy_eff = dy * w * gs;  dw_acc (+)= dy * (gs*(xhat*lw+lb)+bs)  (fp32 accumulator [R,E]).
-template <bool SLN, int NPL>
+template <bool SLN, int NV>
 __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                         int x_bcast_rows, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -118,106 +94,140 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
                                                         bf16* __restrict__ dx, float* __restrict__ part, int part_w,
                                                         const bf16* __restrict__ wmod, const float* __restrict__ gs,
                                                         const float* __restrict__ bs, float* __restrict__ dw_acc,
-                                                        int dw_accumulate, int R, int E, bf16* __restrict__ dxm,
+                                                        int dw_accumulate, int R, bf16* __restrict__ dxm,
                                                         unsigned dthr, unsigned dkey0, float dscale,
                                                         const unsigned* __restrict__ dstep) {
+  constexpr int E = NV * 128;
+  __shared__ float red[3][4][E];
+  __shared__ float reds[4][2];
   const unsigned dkey = vg_drop_key(dkey0, dstep);
-  __shared__ float red[4 * 64 * LN_MAX_PER_LANE];  // [wave][E]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float ag[2 * NPL], ab[2 * NPL], ac[2 * NPL];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane & 15, rg = lane >> 4;
+  float gam[NV][8], lbi[NV][8];
 #pragma unroll
-  for (int i = 0; i < 2 * NPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
-  float s_gs = 0.f, s_bs = 0.f;
-  const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
-  // rows are dealt to (workgroup, wave) pairs round-robin: wave w of block b takes rows
-  // 4*b + w, 4*b + w + 4*gridDim.x, ...  (fixed assignment -> deterministic partial sums)
-  for (int row = blockIdx.x * 4 + w; row < R; row += 4 * gridDim.x) {
-    const int xrow = x_bcast_rows > 0 ? row % x_bcast_rows : row;
-    const bf16x2* xr = (const bf16x2*)(x + (size_t)xrow * E);
-    const bf16x2* dr = (const bf16x2*)(dy + (size_t)row * E);
-    const float mu = mean[row], rs = rstd[row];
-    float xh[2 * NPL], gg[2 * NPL];
-    float c1 = 0.f, c2 = 0.f;
+  for (int i = 0; i < NV; ++i) {
+    const int c = 8 * (sub + 16 * i);
+    const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
 #pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      {
-        const int c = 2 * (lane + 64 * i);
-        const bf16x2 xv = xr[lane + 64 * i];
-        const bf16x2 dv = dr[lane + 64 * i];
-        float d0 = vg_bf2f(dv[0]), d1 = vg_bf2f(dv[1]);
-        const float h0 = (vg_bf2f(xv[0]) - mu) * rs, h1 = (vg_bf2f(xv[1]) - mu) * rs;
-        if (SLN) {
-          const bf16x2 wv = ((const bf16x2*)(wmod + (size_t)row * E))[lane + 64 * i];
-          const float w0 = vg_bf2f(wv[0]), w1 = vg_bf2f(wv[1]);
-          const float l0 = h0 * gamma[c] + lbias[c], l1 = h1 * gamma[c + 1] + lbias[c + 1];
-          float* dwp = dw_acc + (size_t)row * E + c;
-          const float t0 = d0 * (g_s * l0 + b_s), t1 = d1 * (g_s * l1 + b_s);
-          if (dw_accumulate) { dwp[0] += t0; dwp[1] += t1; } else { dwp[0] = t0; dwp[1] = t1; }
-          s_gs += d0 * w0 * l0 + d1 * w1 * l1;
-          s_bs += d0 * w0 + d1 * w1;
-          d0 *= w0 * g_s; d1 *= w1 * g_s;
-        }
-        xh[2 * i] = h0; xh[2 * i + 1] = h1;
-        ag[2 * i] += d0 * h0; ag[2 * i + 1] += d1 * h1;
-        ab[2 * i] += d0; ab[2 * i + 1] += d1;
-        const float g0 = d0 * gamma[c], g1 = d1 * gamma[c + 1];
-        gg[2 * i] = g0; gg[2 * i + 1] = g1;
-        c1 += g0 + g1;
-        c2 += g0 * h0 + g1 * h1;
-      }
-    c1 = vg_wave_sum(c1) / (float)E;
-    c2 = vg_wave_sum(c2) / (float)E;
-    bf16x2* oxr = (bf16x2*)(dx + (size_t)row * E);
+    for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; }
+    if (SLN) {
+      const f32x4 l0 = *(const f32x4*)(lbias + c), l1 = *(const f32x4*)(lbias + c + 4);
 #pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      {
-        float o0 = rs * (gg[2 * i] - c1 - xh[2 * i] * c2);
-        float o1 = rs * (gg[2 * i + 1] - c1 - xh[2 * i + 1] * c2);
-        if (gres) {
-          const bf16x2 rv = ((const bf16x2*)(gres + (size_t)row * E))[lane + 64 * i];
-          o0 += vg_bf2f(rv[0]); o1 += vg_bf2f(rv[1]);
-        }
-        bf16x2 o; o[0] = vg_f2bf(o0); o[1] = vg_f2bf(o1);
-        oxr[lane + 64 * i] = o;
-        if (dxm) {  // gradient entering the dropped branch: dx * mask / keep  (same mask as the forward epilogue)
-          const unsigned idx = (unsigned)row * (unsigned)E + 2u * (lane + 64 * i);
-          const unsigned wd = vg_drop_word(dkey, idx >> 2);
-          bf16x2 om;
-          om[0] = vg_f2bf(vg_bf2f(o[0]) * vg_drop_factor(wd, idx & 3, dthr, dscale));
-          om[1] = vg_f2bf(vg_bf2f(o[1]) * vg_drop_factor(wd, (idx & 3) + 1, dthr, dscale));
-          ((bf16x2*)(dxm + (size_t)row * E))[lane + 64 * i] = om;
-          o = om;
-        }
-        ac[2 * i] += vg_bf2f(o[0]); ac[2 * i + 1] += vg_bf2f(o[1]);
-      }
-  }
-  // fold the 4 waves in a fixed order through LDS (reuse `red` as [4][E] three times)
-  float* rp = red;
-  float* out = part + (size_t)blockIdx.x * part_w;
-#pragma unroll 1
-  for (int which = 0; which < 3; ++which) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      {
-        const int c = 2 * (lane + 64 * i);
-        const float a0 = which == 0 ? ag[2 * i] : (which == 1 ? ab[2 * i] : ac[2 * i]);
-        const float a1 = which == 0 ? ag[2 * i + 1] : (which == 1 ? ab[2 * i + 1] : ac[2 * i + 1]);
-        rp[w * E + c] = a0; rp[w * E + c + 1] = a1;
-      }
-    __syncthreads();
-    for (int c = threadIdx.x; c < E; c += 256) out[which * E + c] = rp[c] + rp[E + c] + rp[2 * E + c] + rp[3 * E + c];
-  }
-  if (SLN) {
-    s_gs = vg_wave_sum(s_gs); s_bs = vg_wave_sum(s_bs);
-    __syncthreads();
-    if (lane == 0) { rp[2 * w] = s_gs; rp[2 * w + 1] = s_bs; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      out[3 * E] = rp[0] + rp[2] + rp[4] + rp[6];
-      out[3 * E + 1] = rp[1] + rp[3] + rp[5] + rp[7];
+      for (int j = 0; j < 4; ++j) { lbi[i][j] = l0[j]; lbi[i][j + 4] = l1[j]; }
     }
   }
+  float ag[NV][8], ab[NV][8], ac[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
+  float s_gs = 0.f, s_bs = 0.f;
+  const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
+  for (int row0 = (blockIdx.x * 4 + wv) * 4; row0 < R; row0 += 16 * gridDim.x) {
+    const int row = row0 + rg;
+    const bool ok = row < R;
+    const int rr = ok ? row : 0;
+    const int xrow = x_bcast_rows > 0 ? rr % x_bcast_rows : rr;
+    const float mu = mean[rr], rs = rstd[rr];
+    float xh[NV][8], gg[NV][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 8 * (sub + 16 * i);
+      float xv[8], dv[8];
+      bf16x8 tx = {0, 0, 0, 0, 0, 0, 0, 0}, td = tx;
+      if (ok) { tx = *(const bf16x8*)(x + (size_t)xrow * E + c); td = *(const bf16x8*)(dy + (size_t)rr * E + c); }
+      unpack8(tx, xv); unpack8(td, dv);
+      float wm[8];
+      if (SLN) {
+        bf16x8 tw = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) tw = *(const bf16x8*)(wmod + (size_t)rr * E + c);
+        unpack8(tw, wm);
+      }
+      float dwv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float h = ok ? (xv[j] - mu) * rs : 0.f;
+        float d = dv[j];
+        if (SLN) {
+          const float l = h * gam[i][j] + lbi[i][j];
+          dwv[j] = d * (g_s * l + b_s);
+          s_gs += d * wm[j] * l;
+          s_bs += d * wm[j];
+          d *= wm[j] * g_s;
+        }
+        xh[i][j] = h;
+        ag[i][j] += d * h;
+        ab[i][j] += d;
+        const float g = d * gam[i][j];
+        gg[i][j] = g;
+        c1 += g;
+        c2 += g * h;
+      }
+      if (SLN && ok) {
+        float* dwp = dw_acc + (size_t)rr * E + c;
+        f32x4 w0 = {dwv[0], dwv[1], dwv[2], dwv[3]}, w1 = {dwv[4], dwv[5], dwv[6], dwv[7]};
+        if (dw_accumulate) { w0 += *(const f32x4*)dwp; w1 += *(const f32x4*)(dwp + 4); }
+        *(f32x4*)dwp = w0; *(f32x4*)(dwp + 4) = w1;
+      }
+    }
+    c1 = row16_sum(c1) * (1.0f / E);
+    c2 = row16_sum(c2) * (1.0f / E);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 8 * (sub + 16 * i);
+      float rv[8];
+      if (gres) {
+        bf16x8 tr = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) tr = *(const bf16x8*)(gres + (size_t)rr * E + c);
+        unpack8(tr, rv);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = rs * (gg[i][j] - c1 - xh[i][j] * c2);
+        if (gres) t += rv[j];
+        o[j] = vg_f2bf(t);
+      }
+      if (ok) *(bf16x8*)(dx + (size_t)rr * E + c) = o;
+      if (dxm) {  // gradient entering the dropped branch: dx * mask / keep  (same mask as the forward epilogue)
+        const unsigned i4 = ((unsigned)rr * (unsigned)E + (unsigned)c) >> 2;
+        const unsigned w0 = vg_drop_word(dkey, i4), w1 = vg_drop_word(dkey, i4 + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(vg_bf2f(o[j]) * vg_drop_factor(j < 4 ? w0 : w1, j, dthr, dscale));
+        if (ok) *(bf16x8*)(dxm + (size_t)rr * E + c) = o;
+      }
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ac[i][j] += vg_bf2f(o[j]);
+      }
+    }
+  }
+  // fold: 4 row groups of the wave (shuffles), then the 4 waves (LDS), fixed order
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = ag[i][j], b = ab[i][j], c = ac[i][j];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+      if (rg == 0) {
+        const int col = 8 * (sub + 16 * i) + j;
+        red[0][wv][col] = a; red[1][wv][col] = b; red[2][wv][col] = c;
+      }
+    }
+  if (SLN) {
+    s_gs = vg_wave_sum(s_gs); s_bs = vg_wave_sum(s_bs);
+    if (lane == 0) { reds[wv][0] = s_gs; reds[wv][1] = s_bs; }
+  }
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * part_w;
+  for (int c = threadIdx.x; c < 3 * E; c += 256) {
+    const int which = c / E, col = c - which * E;
+    out[c] = (red[which][0][col] + red[which][1][col]) + (red[which][2][col] + red[which][3][col]);
+  }
+  if (SLN && threadIdx.x < 2) out[3 * E + threadIdx.x] = (reds[0][threadIdx.x] + reds[1][threadIdx.x]) + (reds[2][threadIdx.x] + reds[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -277,33 +287,40 @@ __global__ __launch_bounds__(256) void vg_colsum_bf16_part_kernel(const bf16* __
 }
 
 // ---------------------------------- host launchers ----------------------------------------
+#define NV_SWITCH(E_, CALL)                                                                                 \
+  switch ((E_) >> 7) {                                                                                      \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;         \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;         \
+    default: return -3;                                                                                     \
+  }
 int vg_ln_fwd_launch(const bf16* x, long long xs, const float* gamma, const float* beta, bf16* y, long long ys,
                      float* mean, float* rstd, int R, int E, float eps, hipStream_t st) {
-  if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-  hipLaunchKernelGGL(vg_ln_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, x, xs, gamma, beta, y, ys, mean, rstd, R, E, eps);
+  if ((E & 127) || E > 1024 || R < 1 || (xs & 7) || (ys & 7)) return -3;
+#define LN_FWD(NV_) hipLaunchKernelGGL((vg_ln_fwd_kernel<false, NV_>), dim3((R + 15) / 16), dim3(256), 0, st, x, xs, 0, (const bf16*)nullptr, \
+                                       gamma, beta, (const float*)nullptr, (const float*)nullptr, y, ys, mean, rstd, R, eps)
+  NV_SWITCH(E, LN_FWD)
+#undef LN_FWD
   return (int)hipGetLastError();
 }
 int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const float* lw, const float* lb,
                       const float* gs, const float* bs, bf16* y, float* mean, float* rstd, int R, int E, float eps,
                       hipStream_t st) {
-  if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-  hipLaunchKernelGGL(vg_sln_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, h, h_bcast_rows, wmod, lw, lb, gs, bs, y,
-                     mean, rstd, R, E, eps);
+  if ((E & 127) || E > 1024 || R < 1) return -3;
+#define SLN_FWD(NV_) hipLaunchKernelGGL((vg_ln_fwd_kernel<true, NV_>), dim3((R + 15) / 16), dim3(256), 0, st, h, (long long)E, h_bcast_rows, wmod, \
+                                        lw, lb, gs, bs, y, (long long)E, mean, rstd, R, eps)
+  NV_SWITCH(E, SLN_FWD)
+#undef SLN_FWD
   return (int)hipGetLastError();
 }
-int vg_ln_bwd_nparts(int R) { const int n = (R + 7) / 8; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
+int vg_ln_bwd_nparts(int R) { const int n = (R + 15) / 16; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
                      float dscale, const unsigned* dstep, hipStream_t st) {
-  if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-#define LN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
+  if ((E & 127) || E > 1024 || R < 1) return -3;
+#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
-                     (const float*)nullptr, (float*)nullptr, 0, R, E, dxm, dthr, dkey, dscale, dstep)
-  switch (E >> 7) {
-    case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
-    case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; case 8: LN_BWD(8); break;
-    default: return -3;
-  }
+                     (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep)
+  NV_SWITCH(E, LN_BWD)
 #undef LN_BWD
   return (int)hipGetLastError();
 }
@@ -311,14 +328,10 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
                       bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st) {
-  if ((E & 127) || E > 64 * LN_MAX_PER_LANE || R < 1) return -3;
-#define SLN_BWD(NPL_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NPL_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
-                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, E, dhm, dthr, dkey, dscale, dstep)
-  switch (E >> 7) {
-    case 1: SLN_BWD(1); break; case 2: SLN_BWD(2); break; case 3: SLN_BWD(3); break; case 4: SLN_BWD(4); break;
-    case 5: SLN_BWD(5); break; case 6: SLN_BWD(6); break; case 7: SLN_BWD(7); break; case 8: SLN_BWD(8); break;
-    default: return -3;
-  }
+  if ((E & 127) || E > 1024 || R < 1) return -3;
+#define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
+                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, dhm, dthr, dkey, dscale, dstep)
+  NV_SWITCH(E, SLN_BWD)
 #undef SLN_BWD
   return (int)hipGetLastError();
 }
