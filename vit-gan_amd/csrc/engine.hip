@@ -194,7 +194,8 @@ struct VitWs {
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf;
   // backward scratch, one set per block parity (block l uses set l&1; its LN1 backward writes gin/gm2 of set (l-1)&1):
   // the weight-gradient side of block l still reads set l&1 while the main stream works on block l-1 in the other set
-  struct Set { bf16 *gin, *gm2, *gmid, *gm1, *dz1, *dqkv; float *part1, *part2; } set[2];
+  struct Set { bf16 *gin, *gm2, *gmid, *gm1, *dz1, *dqkv; } set[2];
+  float* lnpart;  // [2L] LayerNorm-backward partial-sum blocks, folded by one launch at the end of a backward call
   bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *tok_sum, *slab;
 };
@@ -223,9 +224,8 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
     t.gmid = c.take<bf16>(M * E); t.gm1 = c.take<bf16>(M * E);  // same after the MLP half of the block
     t.dz1 = c.take<bf16>(M * rE);
     t.dqkv = c.take<bf16>(M * 3 * E);
-    t.part1 = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
-    t.part2 = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
   }
+  w.lnpart = c.take<float>(2 * L * (long long)vg_ln_bwd_nparts((int)M) * 3 * E);
   w.dxn = c.take<bf16>(M * E);
   w.dao = c.take<bf16>(M * E);
   w.gp = c.take<bf16>(B * NP * E);
@@ -343,6 +343,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   }
 
   int last_side = -1;  // highest-index side event recorded by this call (for the join)
+  VgFoldJobs folds; folds.n = 0;
+  const size_t part_sz = (size_t)lnparts * 3 * E;
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage < stage_begin) continue;
@@ -358,13 +360,15 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* a1 = w.a1 + (size_t)l * M * rE;
     VitWs::Set& cur = w.set[l & 1];
     VitWs::Set& nxt = w.set[(l & 1) ^ 1];  // receives dL/dX[l] for block l-1
+    float* part2 = w.lnpart + (size_t)(2 * l) * part_sz;
+    float* part1 = w.lnpart + (size_t)(2 * l + 1) * part_sz;
     const bf16* g = cur.gin;
     const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
     // ---------------- input-gradient chain (main stream) ----------------
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
     VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, cur.part2, M, E,
+    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, part2, M, E,
                             drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
@@ -374,7 +378,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     // weight-gradient side of block l+1 may still be reading: wait for it first
     if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
       VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[l + 1], 0));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, cur.part1, M, E,
+    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, part1, M, E,
                             drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
     if (!want_wgrad) continue;
     // ---------------- weight-gradient side (second stream when a context is given) ----------------
@@ -384,7 +388,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     }
     if (l == top) VG_TRY(vg_colsum_bf16_launch(gb2, E, M, E, w.part_cs, G + lo + lay.b2, 1, sd));  // lower blocks: from LN1's partials
     VG_TRY(vg_colsum_bf16_launch(cur.dz1, rE, M, rE, w.part_cs, G + lo + lay.b1, 1, sd));
-    VG_TRY(vg_colsum_f32_launch(cur.part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0, 1, sd));
+    vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0);
     VG_TRY(vg_colsum_bf16_launch(cur.dqkv, 3 * E, M, 3 * E, w.part_cs, G + lo + lay.bqkv, 1, sd));
     {
       // the four weight gradients of the block as ONE grouped split-K launch
@@ -400,9 +404,14 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     }
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
-      VG_TRY(vg_colsum_f32_launch(cur.part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0, 1, sd));
+      vg_fold_push(folds, part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0);
     }
     if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_side[l], sd)); last_side = l; }
+  }
+  // all LayerNorm partial sums of this call in one launch (behind the last block's side work)
+  if (folds.n > 0) {
+    VG_TRY(vg_colsum_f32_multi_launch(folds, sd));
+    if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_side[VG_CTX_EVENTS - 1], sd)); VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[VG_CTX_EVENTS - 1], 0)); }
   }
   // join: everything this call put on the side stream is ordered before whatever follows on the main stream
   if (ctx && last_side >= 0) VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[last_side], 0));
@@ -475,7 +484,7 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.dqkv = c.take<bf16>(R * 3 * E);
   w.dwb = c.take<bf16>(R * E);
   w.dw_acc = c.take<float>(R * E);
-  w.part = c.take<float>((long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));
+  w.part = c.take<float>((2 * L + 1) * (long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));  // one block per SLN backward
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
   w.emb_sum = c.take<float>(T * E);
   long long slab = GEN_SPLIT_CAP * lay.layer_weights;
@@ -553,6 +562,8 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   const size_t RE = (size_t)R * E;
   const float scale = 1.0f / sqrtf((float)E);
   const int parts = vg_ln_bwd_nparts(R);
+  const size_t part_sz = (size_t)parts * PW;
+  VgFoldJobs folds; folds.n = 0;
   const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
   const bool drop = dr.thr != 0;
   bf16* const gm2buf = w.gm[0];  // g masked for the MLP-branch dropout it meets next
@@ -579,10 +590,10 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
-                           nullptr, g, w.dw_acc, 0, w.part, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
+                           nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
   {
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
-    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2, 1, st));
+    vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2);
   }
   for (int l = d.L - 1; l >= 0; --l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
@@ -597,11 +608,11 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     const bf16* gb2 = drop ? gm2buf : g;
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_sln_bwd_launch(w.ds, htmp, 0, w.wmod, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w,
-                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part, R, E,
+                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part + (size_t)(2 * l) * part_sz, R, E,
                              drop ? gm1buf : nullptr, dr.thr, site_key(dr, 100 + 2 * l), dr.scale, dr.step, st));
     const bf16* gb1 = drop ? gm1buf : gmid;
-    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
-                                G + lo + lay.sln2_s, 2, 1, st));
+    vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
+                 G + lo + lay.sln2_s, 2);
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, st));
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
@@ -616,12 +627,13 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
     }
     VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
-                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part, R, E,
+                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part + (size_t)(2 * l + 1) * part_sz, R, E,
                              (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
     float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
-    VG_TRY(vg_colsum_f32_launch(w.part, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2, 1, st));
+    vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2);
     bf16* t = g; g = gin; gin = t;
   }
+  VG_TRY(vg_colsum_f32_multi_launch(folds, st));  // all SLN partial sums in one launch
   // learned embedding (generator.py:24-26,62) is broadcast over the batch: its gradient is the batch sum
   VG_TRY(vg_batch_sum_launch(g, w.emb_sum, B, T, E, st));
   VG_TRY(vg_slab_reduce_launch(w.emb_sum, 0, 1, G + lay.emb, (long long)T * E, 1, st));

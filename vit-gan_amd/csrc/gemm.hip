@@ -411,11 +411,14 @@ __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return -1;
   // tile height: 256 rows (8 waves) when every problem is tall enough to fill the chip that way
-  // 256-row tiles (8 waves) for tall problems with a light epilogue; transcendental epilogues (GELU, gelu',
-  // sin, cos) run better on 128-row tiles, where more co-resident workgroups overlap that VALU work.
+  // 256-row tiles (8 waves, 2 workgroups/CU) only when they still give every CU its two workgroups (>= 512 tiles)
+  // and the epilogue is light; otherwise 128-row tiles (4 workgroups/CU): small problems (generator, M = 8192)
+  // and transcendental epilogues (GELU, gelu', sin, cos) need the extra workgroups to fill / overlap.
   int wm4 = 1;
-  for (int i = 0; i < n; ++i)
-    if (probs[i].M < 4096 || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long t4 = (long long)((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
+    if (t4 < 512 || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
+  }
   if (const char* e = getenv("VG_GEMM_WM")) wm4 = (atoi(e) == 4) && mode != VG_TN;
   const int bm = wm4 ? 256 : 128;
   static const bool dbg_nostore = getenv("VG_GEMM_DEBUG_NOSTORE") != nullptr;  // timing experiments only

@@ -86,7 +86,31 @@ __global__ __launch_bounds__(256) void vg_ln_fwd_kernel(const bf16* __restrict__
 //   part[wg][3E], [3E+1] = SLN scalars d gs, d bs      (SLN only; width 3E+64)
 // dx = (gres ? gres : 0) + LN-backward(dy_eff);  dxm = dx * dropout mask (optional second output).
 // SLN: dy_eff = dy * w * gs;  dw_acc (+)= dy * (gs*(xhat*lw+lb)+bs)  (fp32 accumulator [R,E]).
-template <bool SLN, int NV>
+template <int CH> struct ChunkT;
+template <> struct ChunkT<8> { typedef bf16x8 bt; };
+template <> struct ChunkT<4> { typedef bf16x4 bt; };
+template <int CH>
+__device__ __forceinline__ void ld_chunk(const bf16* p, bool ok, float (&o)[CH]) {
+  typename ChunkT<CH>::bt t;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) t[j] = (bf16)0.f;
+  if (ok) t = *(const typename ChunkT<CH>::bt*)p;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) o[j] = vg_bf2f(t[j]);
+}
+template <int CH>
+__device__ __forceinline__ void ld_f32(const float* p, float (&o)[CH]) {
+#pragma unroll
+  for (int q = 0; q < CH / 4; ++q) {
+    const f32x4 t = *(const f32x4*)(p + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[4 * q + j] = t[j];
+  }
+}
+
+// LPR lanes per row (16: 16-byte chunks, 4 rows per wave; 32: 8-byte chunks, 2 rows per wave - half the
+// per-lane state, used where the backward's accumulators would otherwise cap occupancy at 1-2 waves/SIMD).
+template <bool SLN, int NV, int LPR>
 __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                         int x_bcast_rows, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -97,60 +121,43 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
                                                         int dw_accumulate, int R, bf16* __restrict__ dxm,
                                                         unsigned dthr, unsigned dkey0, float dscale,
                                                         const unsigned* __restrict__ dstep) {
-  constexpr int E = NV * 128;
+  constexpr int E = NV * 128, CH = 128 / LPR, RPW = 64 / LPR;
   __shared__ float red[3][4][E];
   __shared__ float reds[4][2];
   const unsigned dkey = vg_drop_key(dkey0, dstep);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int sub = lane & 15, rg = lane >> 4;
-  float gam[NV][8], lbi[NV][8];
+  const int sub = lane % LPR, rg = lane / LPR;
+  float gam[NV][CH];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = 8 * (sub + 16 * i);
-    const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; }
-    if (SLN) {
-      const f32x4 l0 = *(const f32x4*)(lbias + c), l1 = *(const f32x4*)(lbias + c + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { lbi[i][j] = l0[j]; lbi[i][j + 4] = l1[j]; }
-    }
-  }
-  float ag[NV][8], ab[NV][8], ac[NV][8];
+  for (int i = 0; i < NV; ++i) ld_f32<CH>(gamma + CH * (sub + LPR * i), gam[i]);
+  float ag[NV][CH], ab[NV][CH], ac[NV][CH];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
+    for (int j = 0; j < CH; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
   float s_gs = 0.f, s_bs = 0.f;
   const float g_s = SLN ? gs[0] : 1.f, b_s = SLN ? bs[0] : 0.f;
-  for (int row0 = (blockIdx.x * 4 + wv) * 4; row0 < R; row0 += 16 * gridDim.x) {
+  for (int row0 = (blockIdx.x * 4 + wv) * RPW; row0 < R; row0 += 4 * RPW * gridDim.x) {
     const int row = row0 + rg;
     const bool ok = row < R;
     const int rr = ok ? row : 0;
     const int xrow = x_bcast_rows > 0 ? rr % x_bcast_rows : rr;
     const float mu = mean[rr], rs = rstd[rr];
-    float xh[NV][8], gg[NV][8];
+    float xh[NV][CH], gg[NV][CH];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = 8 * (sub + 16 * i);
-      float xv[8], dv[8];
-      bf16x8 tx = {0, 0, 0, 0, 0, 0, 0, 0}, td = tx;
-      if (ok) { tx = *(const bf16x8*)(x + (size_t)xrow * E + c); td = *(const bf16x8*)(dy + (size_t)rr * E + c); }
-      unpack8(tx, xv); unpack8(td, dv);
-      float wm[8];
-      if (SLN) {
-        bf16x8 tw = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) tw = *(const bf16x8*)(wmod + (size_t)rr * E + c);
-        unpack8(tw, wm);
-      }
-      float dwv[8];
+      const int c = CH * (sub + LPR * i);
+      float xv[CH], dv[CH], wm[CH], lbi[CH], dwv[CH];
+      ld_chunk<CH>(x + (size_t)xrow * E + c, ok, xv);
+      ld_chunk<CH>(dy + (size_t)rr * E + c, ok, dv);
+      if (SLN) { ld_chunk<CH>(wmod + (size_t)rr * E + c, ok, wm); ld_f32<CH>(lbias + c, lbi); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < CH; ++j) {
         const float h = ok ? (xv[j] - mu) * rs : 0.f;
         float d = dv[j];
         if (SLN) {
-          const float l = h * gam[i][j] + lbi[i][j];
+          const float l = h * gam[i][j] + lbi[j];
           dwv[j] = d * (g_s * l + b_s);
           s_gs += d * wm[j] * l;
           s_bs += d * wm[j];
@@ -166,54 +173,56 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
       }
       if (SLN && ok) {
         float* dwp = dw_acc + (size_t)rr * E + c;
-        f32x4 w0 = {dwv[0], dwv[1], dwv[2], dwv[3]}, w1 = {dwv[4], dwv[5], dwv[6], dwv[7]};
-        if (dw_accumulate) { w0 += *(const f32x4*)dwp; w1 += *(const f32x4*)(dwp + 4); }
-        *(f32x4*)dwp = w0; *(f32x4*)(dwp + 4) = w1;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          f32x4 w0 = {dwv[4 * q], dwv[4 * q + 1], dwv[4 * q + 2], dwv[4 * q + 3]};
+          if (dw_accumulate) w0 += *(const f32x4*)(dwp + 4 * q);
+          *(f32x4*)(dwp + 4 * q) = w0;
+        }
       }
     }
-    c1 = row16_sum(c1) * (1.0f / E);
-    c2 = row16_sum(c2) * (1.0f / E);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    c1 *= (1.0f / E); c2 *= (1.0f / E);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = 8 * (sub + 16 * i);
-      float rv[8];
-      if (gres) {
-        bf16x8 tr = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) tr = *(const bf16x8*)(gres + (size_t)rr * E + c);
-        unpack8(tr, rv);
-      }
-      bf16x8 o;
+      const int c = CH * (sub + LPR * i);
+      float rv[CH];
+      if (gres) ld_chunk<CH>(gres + (size_t)rr * E + c, ok, rv);
+      typename ChunkT<CH>::bt o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < CH; ++j) {
         float t = rs * (gg[i][j] - c1 - xh[i][j] * c2);
         if (gres) t += rv[j];
         o[j] = vg_f2bf(t);
       }
-      if (ok) *(bf16x8*)(dx + (size_t)rr * E + c) = o;
+      if (ok) *(typename ChunkT<CH>::bt*)(dx + (size_t)rr * E + c) = o;
       if (dxm) {  // gradient entering the dropped branch: dx * mask / keep  (same mask as the forward epilogue)
         const unsigned i4 = ((unsigned)rr * (unsigned)E + (unsigned)c) >> 2;
-        const unsigned w0 = vg_drop_word(dkey, i4), w1 = vg_drop_word(dkey, i4 + 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(vg_bf2f(o[j]) * vg_drop_factor(j < 4 ? w0 : w1, j, dthr, dscale));
-        if (ok) *(bf16x8*)(dxm + (size_t)rr * E + c) = o;
+        for (int q = 0; q < CH / 4; ++q) {
+          const unsigned wd = vg_drop_word(dkey, i4 + q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * q + j] = vg_f2bf(vg_bf2f(o[4 * q + j]) * vg_drop_factor(wd, j, dthr, dscale));
+        }
+        if (ok) *(typename ChunkT<CH>::bt*)(dxm + (size_t)rr * E + c) = o;
       }
       if (ok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ac[i][j] += vg_bf2f(o[j]);
+        for (int j = 0; j < CH; ++j) ac[i][j] += vg_bf2f(o[j]);
       }
     }
   }
-  // fold: 4 row groups of the wave (shuffles), then the 4 waves (LDS), fixed order
+  // fold: the RPW row groups of the wave (shuffles), then the 4 waves (LDS), fixed order
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < CH; ++j) {
       float a = ag[i][j], b = ab[i][j], c = ac[i][j];
-      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
       if (rg == 0) {
-        const int col = 8 * (sub + 16 * i) + j;
+        const int col = CH * (sub + LPR * i) + j;
         red[0][wv][col] = a; red[1][wv][col] = b; red[2][wv][col] = c;
       }
     }
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------
 // dst_k[c] (+)= sum_r part[r][off_k + c]  for up to 4 consecutive column segments.
 struct VgSeg { float* dst; int n; };
+#include "vg_fold.h"
 struct VgSegs { VgSeg s[4]; };
 __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restrict__ part, int rows, int width,
                                                             VgSegs segs, int accumulate) {
@@ -256,6 +266,33 @@ __global__ __launch_bounds__(256) void vg_colsum_f32_kernel(const float* __restr
   }
   if (!dst) return;
   if (accumulate) *dst += a; else *dst = a;
+}
+
+// Many folds in ONE launch (blockIdx.y = job): the backward passes queue one job per LayerNorm and fold them all
+// at the end instead of paying a ~10 us latency-bound launch per LayerNorm.
+__global__ __launch_bounds__(256) void vg_colsum_f32_multi_kernel(VgFoldJobs jobs) {
+  __shared__ float red[16][17];
+  const VgFoldJob& J = jobs.j[blockIdx.y];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int width = J.width, rows = J.rows;
+  if (blockIdx.x * 16 >= width) return;
+  float a = 0.f;
+  if (c < width)
+    for (int r = rl; r < rows; r += 16) a += J.part[(size_t)r * width + c];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl != 0 || c >= width) return;
+  a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a += red[k][cl];
+  int off = 0; float* dst = nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (c >= off && c < off + J.n[k]) dst = J.dst[k] ? J.dst[k] + (c - off) : nullptr;
+    off += J.n[k];
+  }
+  if (dst) *dst += a;
 }
 
 // partial column sums of a bf16 matrix: part[chunk][c] = sum over the chunk's rows of X[r][c].
@@ -312,12 +349,13 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 #undef SLN_FWD
   return (int)hipGetLastError();
 }
+// one partial row per workgroup: 16 rows per workgroup pass, at most LN_MAX_PARTS workgroups (bandwidth-bound: wants many)
 int vg_ln_bwd_nparts(int R) { const int n = (R + 15) / 16; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
                      float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 1024 || R < 1) return -3;
-#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
+#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, 16>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
                      (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep)
   NV_SWITCH(E, LN_BWD)
@@ -329,7 +367,7 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
                       bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 1024 || R < 1) return -3;
-#define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
+#define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_, 16>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
                      rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, dhm, dthr, dkey, dscale, dstep)
   NV_SWITCH(E, SLN_BWD)
 #undef SLN_BWD
@@ -339,6 +377,14 @@ int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int 
                          float* d3, int n3, int accumulate, hipStream_t st) {
   VgSegs s; s.s[0] = {d0, n0}; s.s[1] = {d1, n1}; s.s[2] = {d2, n2}; s.s[3] = {d3, n3};
   hipLaunchKernelGGL(vg_colsum_f32_kernel, dim3((width + 15) / 16), dim3(256), 0, st, part, rows, width, s, accumulate);
+  return (int)hipGetLastError();
+}
+int vg_colsum_f32_multi_launch(const VgFoldJobs& jobs, hipStream_t st) {
+  if (jobs.n < 1) return 0;
+  if (jobs.n > VG_MAX_FOLD_JOBS) return -1;
+  int wmax = 0;
+  for (int i = 0; i < jobs.n; ++i) wmax = jobs.j[i].width > wmax ? jobs.j[i].width : wmax;
+  hipLaunchKernelGGL(vg_colsum_f32_multi_kernel, dim3((wmax + 15) / 16, jobs.n), dim3(256), 0, st, jobs);
   return (int)hipGetLastError();
 }
 int vg_colsum_bf16_nparts(int R) { return (R + CS_ROWS - 1) / CS_ROWS; }

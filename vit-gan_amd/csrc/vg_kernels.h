@@ -22,6 +22,8 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st);
 int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1, float* d2, int n2,
                          float* d3, int n3, int accumulate, hipStream_t st);
+#include "vg_fold.h"
+int vg_colsum_f32_multi_launch(const VgFoldJobs& jobs, hipStream_t st);
 int vg_colsum_bf16_nparts(int R);
 int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
                           hipStream_t st);
