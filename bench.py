@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +131,8 @@ def main():
     D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
     G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
     use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
-    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank)
+    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
+                    concurrent_wgrad=not args.single_stream)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream

@@ -388,6 +388,12 @@ int vg_colsum_f32_multi_launch(const VgFoldJobs& jobs, hipStream_t st) {
   return (int)hipGetLastError();
 }
 int vg_colsum_bf16_nparts(int R) { return (R + CS_ROWS - 1) / CS_ROWS; }
+// first stage only: part[chunk][N] partial sums, to be folded later (vg_colsum_f32 / a queued VgFoldJob)
+int vg_colsum_bf16_part_launch(const bf16* X, long long ld, int R, int N, float* part, hipStream_t st) {
+  if ((N & 7) || (ld & 7) || R < 1) return -3;
+  hipLaunchKernelGGL(vg_colsum_bf16_part_kernel, dim3((N + 255) / 256, vg_colsum_bf16_nparts(R)), dim3(256), 0, st, X, ld, R, N, part);
+  return (int)hipGetLastError();
+}
 // dst[c] (+)= sum_r X[r][c]; `part` needs vg_colsum_bf16_nparts(R) * N floats of scratch.
 int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
                           hipStream_t st) {

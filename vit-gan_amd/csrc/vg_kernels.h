@@ -25,6 +25,7 @@ int vg_colsum_f32_launch(const float* part, int rows, int width, float* d0, int 
 #include "vg_fold.h"
 int vg_colsum_f32_multi_launch(const VgFoldJobs& jobs, hipStream_t st);
 int vg_colsum_bf16_nparts(int R);
+int vg_colsum_bf16_part_launch(const bf16* X, long long ld, int R, int N, float* part, hipStream_t st);
 int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part, float* dst, int accumulate,
                           hipStream_t st);
 
