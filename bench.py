@@ -47,7 +47,7 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def gemm_roofline(torch, B):
-    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<NN,4,...>,
+    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<1, 2, 0, 0>,
     the input-gradient GEMM; timed at its heaviest shape, the QKV dgrad of the fused real+fake pass:
     dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.  Average launch duration is measured live with HIP
     events on the stream the kernel runs on; achieved = algorithmic FLOPs (2*M*N*K) / that duration.
@@ -83,7 +83,7 @@ def gemm_roofline(torch, B):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "kernel": "vg_gemm_kernel<NN, 256x128 tile> (QKV input gradient)", "shape_M_N_K": [M, K, N],
+            "traffic": traffic, "kernel": "vg_gemm_kernel<1, 2, 0, 0> = NN input-gradient GEMM, 128x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
             "algorithmic_flops_per_launch": 2.0 * M * N * K, "algorithmic_bytes_per_launch": 2 * (M * N + N * K + M * K),
             "avg_launch_us": round(ms * 1e3, 2)}
 
@@ -100,7 +100,15 @@ def main():
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
+    ap.add_argument("--roofline-only", action="store_true", help="profiling aid: run only the dominant-kernel timing leg and print its object")
     args = ap.parse_args()
+    if args.roofline_only:
+        import torch
+        import vit_gan_amd  # noqa: F401
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+        print(json.dumps({"roofline": gemm_roofline(torch, args.batch)}))
+        return
 
     import torch
     import torch.distributed as dist

@@ -31,7 +31,7 @@ def p(t):
 
 
 B = int(os.environ.get("B", "512"))
-M = B * 65
+M = int(os.environ.get("M", B * 65))
 for (N, K, act, pre, res, nm) in [(1152, 384, 0, False, False, "NT qkv"), (384, 384, 0, False, True, "NT out+res"),
                                   (768, 384, 1, True, False, "NT fc1+gelu+pre"), (384, 768, 0, False, True, "NT fc2+res")]:
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)

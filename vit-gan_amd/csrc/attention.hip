@@ -1,6 +1,8 @@
 // Fused multi-head self-attention (forward and backward) for short sequences (S <= 80): one workgroup
-// per (image, head), ONE WAVE PER 16-ROW TILE (5 waves for S = 65) so that a CU holds 15-20 waves -
-// these kernels are latency bound and occupancy is what hides it.  gfx950 only.
+// per (image, head), ONE WAVE PER 16-ROW TILE (5 waves for S = 65).  gfx950 only.
+// These kernels are HBM/latency bound (4 % of the step's FLOPs): every operand of a head is staged into LDS
+// exactly once by LDS-DMA in a single load phase, everything is computed from LDS, and the outputs leave as
+// 16-byte stores; the co-resident workgroups of a CU overlap each other's load / compute / store phases.
 //
 // The whole S x S score tile lives in MFMA accumulators; softmax runs in registers.
 // Layout trick (cdna_hip_programming.md s3, "an accumulator tile as the next MFMA's operand"):
@@ -13,24 +15,62 @@
 // columns h*HE .. (h+1)*HE of each third.  o / d_o: [B*S, E].  lse: [B, H, S] fp32 (natural log).
 #include "vg_common.h"
 
+// LDS image of one head: row-major [rows][HE] bf16 whose 16-B chunks are XOR-swizzled by the row so that BOTH
+// access patterns are bank-conflict free:
+//   row form   (ds_read_b128, 16 lanes = 16 consecutive rows, same chunk)   and
+//   transposed (ds_read_b64_tr_b16, 32 lanes = 8 consecutive rows x one 32-B chunk pair).
+// HE = 96 / 32 (row pitch 48 / 16 banks: rows r and r+4 share a bank quadrant): position inside each 64-B window
+//   is XORed with F[(r>>2)&3], F = {0,2,1,3} - rows r+4 move to the other pair, rows r+8 / r+12 swap halves.
+// HE = 64 (pitch 32 banks: rows r and r+2 collide): pair index ^ (r>>1)&3, half ^ (r>>3)&1.
+// The map is an involution on the chunk index, so the DMA applies the same function to its SOURCE chunk.
+template <int HE>
+__device__ __forceinline__ int swz_chunk(int r, int c) {
+  if (HE == 64) return (((c >> 1) ^ ((r >> 1) & 3)) << 1) | ((c & 1) ^ ((r >> 3) & 1));
+  const int x = (r >> 2) & 3;
+  return (c & ~3) | ((c & 3) ^ (((x & 1) << 1) | (x >> 1)));
+}
 template <int HE>
 __device__ __forceinline__ int lds_off(int r, int d) {
-  // row-major [rows][HE] bf16 with the 32-B chunk index XOR-swizzled by the row so that the
-  // 8 consecutive rows one half-wave touches in a transposed read fall on 64 distinct banks.
-  const int sw = (HE == 64) ? ((r >> 1) & 3) : ((r >> 2) & 1);  // HE = 96 / 32: rows realign every 4
-  return r * (HE * 2) + ((((d >> 4) ^ sw)) << 5) + ((d & 15) << 1);
+  return r * (HE * 2) + (swz_chunk<HE>(r, d >> 3) << 4) + ((d & 7) << 1);
 }
 
-// stage rows [0, rows_alloc) x HE of one head into LDS; rows >= S are zero-filled
-template <int HE>
-__device__ __forceinline__ void stage_head(unsigned char* lds, const bf16* __restrict__ src, size_t ld,
-                                           int S, int rows_alloc, int tid, int nthreads) {
+// Stage rows [0, rows_alloc) x HE of one head into an LDS image by LDS-DMA (global_load_lds_dwordx4: no trip
+// through registers, every request a whole 16-B chunk of a 64..192-B row segment).  One instruction fills
+// 1 KiB lane-linearly, so LDS chunk (row r, position c') = linear chunk 64*piece + lane and the XOR swizzle
+// (swz_chunk) is applied to the SOURCE chunk index.  Rows >= S come from a 16-byte zero page (the padded keys'
+// V rows multiply p = 0 and must be finite).  rows_alloc * HE / 8 must be a multiple of 64.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int HE, int NW>
+__device__ __forceinline__ void dma_head(unsigned char* img, const bf16* __restrict__ src, size_t ld, int S, int rows_alloc,
+                                         const void* zeros, int wave, int lane) {
   constexpr int CPR = HE / 8;  // 16-B chunks per row
-  for (int idx = tid; idx < rows_alloc * CPR; idx += nthreads) {
-    const int r = idx / CPR, c = idx - r * CPR;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < S) v = *(const u32x4*)(src + (size_t)r * ld + 8 * c);
-    *(u32x4*)(lds + lds_off<HE>(r, 8 * c)) = v;
+  const int pieces = rows_alloc * CPR / 64;
+  for (int pc = wave; pc < pieces; pc += NW) {
+    const int ci = 64 * pc + lane;
+    const int r = ci / CPR, cp = ci - r * CPR;
+    const int c = swz_chunk<HE>(r, cp);
+    const void* p = (r < S) ? (const void*)(src + (size_t)r * ld + 8 * c) : zeros;
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(img + 1024 * pc), 16, 0, 0);
+  }
+}
+
+// Accumulator tiles [dt] (lane = row li, 4 consecutive head-dim columns 16*dt + 4*g ..) -> bf16 row segments.
+// v_permlane16_swap between the even and the odd tile of a pair hands every lane 8 CONSECUTIVE columns, so a lane
+// stores 16 B and a wave-instruction covers 16 rows x 64 B (same exchange as the GEMM epilogue).
+template <int DT>
+__device__ __forceinline__ void store_tiles(bf16* __restrict__ rowp, const f32x4 (&acc)[DT], float mul, int g, bool ok) {
+#pragma unroll
+  for (int pr = 0; pr < DT / 2; ++pr) {
+    const f32x4 te = acc[2 * pr], to = acc[2 * pr + 1];
+    bf16x8 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(te[r] * mul), __float_as_uint(to[r] * mul), false, false);
+      w[r] = vg_f2bf(__uint_as_float(sw[0]));
+      w[r + 4] = vg_f2bf(__uint_as_float(sw[1]));
+    }
+    if (ok) *(bf16x8*)(rowp + 32 * pr + ((g & 1) << 4) + ((g & 2) << 2)) = w;
   }
 }
 
@@ -78,9 +118,12 @@ __device__ __forceinline__ float group_max(float v) {
 
 template <int HE, int NT>
 __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                              float* __restrict__ lse, int S, int H, float scale) {
-  constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char vl[RP * HE * 2];
+                                                              float* __restrict__ lse, int S, int H, float scale,
+                                                              const void* __restrict__ zeros) {
+  constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32, RK = 16 * NT;
+  __shared__ __attribute__((aligned(16))) unsigned char sm[(RK + RP) * HE * 2];
+  unsigned char* kl = sm;                 // K, rows [0, 16 NT): row-form fragments
+  unsigned char* vl = sm + RK * HE * 2;   // V, rows [0, 32 KP): transposed fragments
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6;  // wave qt owns query rows 16*qt .. 16*qt+15
   const int g = lane >> 4, li = lane & 15;
@@ -90,18 +133,20 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
   const bf16* kb = qb + E;
   const bf16* vb = qb + 2 * E;
 
-  stage_head<HE>(vl, vb, ld, S, RP, tid, 64 * NT);
-
-  bf16x8 qf[KS];
+  bf16x8 qf[KS];  // this wave's queries straight from global (nobody else needs them)
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag(qb, ld, 16 * qt, ks, S, lane);
+  dma_head<HE, NT>(kl, kb, ld, S, RK, zeros, qt, lane);
+  dma_head<HE, NT>(vl, vb, ld, S, RP, zeros, (qt + 2) % NT, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   f32x4 sc[NT];  // [kt]: rows = keys 16kt+4g+r, col = query 16qt+li
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a = vg_mfma(gfrag(kb, ld, 16 * kt, ks, S, lane), qf[ks], a);
+    for (int ks = 0; ks < KS; ++ks) a = vg_mfma(lfrag_row<HE>(kl, 16 * kt, ks, lane), qf[ks], a);
     sc[kt] = a;
   }
   const int q = 16 * qt + li;
@@ -129,7 +174,6 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
   const float inv_l = 1.0f / l;
   if (g == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __logf(l);
 
-  __syncthreads();  // V image complete
   f32x4 oa[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) oa[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -140,31 +184,28 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma(lfrag_tr<HE>(vl, u, 16 * dt, lane), pf, oa[dt]);
   }
-  if (q < S) {
-    bf16* op = o + ((size_t)b * S + q) * E + h * HE + 4 * g;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      bf16x4 w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = vg_f2bf(oa[dt][r] * inv_l);
-      *(bf16x4*)(op + 16 * dt) = w;
-    }
-  }
+  store_tiles<DT>(o + ((size_t)b * S + (q < S ? q : 0)) * E + h * HE, oa, inv_l, g, q < S);
 }
 
 // Backward.  Phase A works in the S^T orientation (lane = query) and yields dQ; phase B in the
 // S orientation (lane = key) and yields dK, dV.  Recomputing the 65x65 tile in both orientations
 // costs 2 x 75 extra MFMAs per head and removes every register transpose.
 template <int HE, int NT>
-__global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int S, int H, float scale) {
+                                                         bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                         const void* __restrict__ zeros) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
   constexpr int IMG = RP * HE * 2;
-  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * IMG + RP * 4];
-  unsigned char* l0 = sm;
-  unsigned char* l1 = sm + IMG;
-  float* dl = (float*)(sm + 2 * IMG);  // delta[q] = sum_d dO*O
+  // Everything a head needs is staged ONCE: K, V, Q, dO images (LDS-DMA) + lse and delta per query.  One load
+  // phase, one compute phase, one store phase per workgroup; the co-resident workgroup overlaps them.
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4 * IMG + 2 * RP * 4];
+  unsigned char* lk = sm;
+  unsigned char* lv = sm + IMG;
+  unsigned char* lq = sm + 2 * IMG;
+  unsigned char* ldo = sm + 3 * IMG;
+  float* dl = (float*)(sm + 4 * IMG);  // delta[q] = sum_d dO*O
+  float* ll = dl + RP;                 // lse[q]
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
   const int g = lane >> 4, li = lane & 15;
@@ -179,40 +220,54 @@ __global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __r
   bf16* dqb = dqkv + (size_t)b * S * ld + h * HE;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-  // ---------------- phase A: K, V in LDS; loop over query tiles -> dQ ----------------------
-  stage_head<HE>(l0, kb, ld, S, RP, tid, 64 * NT);
-  stage_head<HE>(l1, vb, ld, S, RP, tid, 64 * NT);
-  for (int i = tid; i < RP; i += 64 * NT) dl[i] = 0.f;
+  bf16x8 of[KS];  // O is only needed for delta: this wave's 16 query rows, straight from global
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) of[ks] = gfrag(ob, (size_t)E, 16 * wv, ks, S, lane);
+  dma_head<HE, NT>(lk, kb, ld, S, RP, zeros, wv, lane);
+  dma_head<HE, NT>(lv, vb, ld, S, RP, zeros, (wv + 1) % NT, lane);
+  dma_head<HE, NT>(lq, qb, ld, S, RP, zeros, (wv + 2) % NT, lane);
+  dma_head<HE, NT>(ldo, dob, (size_t)E, S, RP, zeros, (wv + 3) % NT, lane);
+  for (int i = tid; i < RP; i += 64 * NT) ll[i] = (i < S) ? lb[i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef VG_ATTN_ABL
+  if (VG_ATTN_ABL == 1) { if (tid == 0 && ll[0] == 12345.f) dqb[0] = of[0][0]; return; }
+#endif
+
+  bf16x8 qf[KS], dof[KS];
   {
-    const int qt = wv;
-    const int q = 16 * qt + li;
-    bf16x8 qf[KS], dof[KS];
     float dpart = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      qf[ks] = gfrag(qb, ld, 16 * qt, ks, S, lane);
-      dof[ks] = gfrag(dob, (size_t)E, 16 * qt, ks, S, lane);
-      const bf16x8 of = gfrag(ob, (size_t)E, 16 * qt, ks, S, lane);
+      qf[ks] = lfrag_row<HE>(lq, 16 * wv, ks, lane);
+      dof[ks] = lfrag_row<HE>(ldo, 16 * wv, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dpart += vg_bf2f(dof[ks][j]) * vg_bf2f(of[j]);
+      for (int j = 0; j < 8; ++j) dpart += vg_bf2f(dof[ks][j]) * vg_bf2f(of[ks][j]);
     }
     const float delta = group_sum(dpart);
-    if (g == 0) dl[q] = delta;
-    const float lq = (q < S) ? lb[q] : 0.f;
+    if (g == 0) dl[16 * wv + li] = delta;
+  }
+  __syncthreads();
+
+  // ---------------- phase A: S^T orientation (lane = query) -> dQ ----------------------
+  {
+    const int qt = wv;
+    const int q = 16 * qt + li;
+    const float delta = dl[q];
+    const float lse_q = ll[q];
     f32x4 ds[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       f32x4 st = zero, dpt = zero;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        st = vg_mfma(lfrag_row<HE>(l0, 16 * kt, ks, lane), qf[ks], st);
-        dpt = vg_mfma(lfrag_row<HE>(l1, 16 * kt, ks, lane), dof[ks], dpt);
+        st = vg_mfma(lfrag_row<HE>(lk, 16 * kt, ks, lane), qf[ks], st);
+        dpt = vg_mfma(lfrag_row<HE>(lv, 16 * kt, ks, lane), dof[ks], dpt);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kt + 4 * g + r;
-        const float p = (key < S && q < S) ? __expf(st[r] * scale - lq) : 0.f;
+        const float p = (key < S && q < S) ? __expf(st[r] * scale - lse_q) : 0.f;
         ds[kt][r] = p * (dpt[r] - delta) * scale;
       }
     }
@@ -223,32 +278,19 @@ __global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __r
     for (int u = 0; u < KP; ++u) {
       const bf16x8 dsf = pack_pair(ds[2 * u], (2 * u + 1 < NT) ? ds[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[dt] = vg_mfma(lfrag_tr<HE>(l0, u, 16 * dt, lane), dsf, dq[dt]);
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = vg_mfma(lfrag_tr<HE>(lk, u, 16 * dt, lane), dsf, dq[dt]);
     }
-    if (q < S) {
-      bf16* p = dqb + (size_t)q * ld + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        bf16x4 w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = vg_f2bf(dq[dt][r]);
-        *(bf16x4*)(p + 16 * dt) = w;
-      }
-    }
+    store_tiles<DT>(dqb + (size_t)(q < S ? q : 0) * ld, dq, 1.0f, g, q < S);
   }
-  __syncthreads();
-  // ---------------- phase B: Q, dO in LDS; loop over key tiles -> dK, dV ---------------------
-  stage_head<HE>(l0, qb, ld, S, RP, tid, 64 * NT);
-  stage_head<HE>(l1, dob, (size_t)E, S, RP, tid, 64 * NT);
-  __syncthreads();
+  // ---------------- phase B: S orientation (lane = key) -> dK, dV ---------------------
   {
     const int kt = wv;
     const int key = 16 * kt + li;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      kf[ks] = gfrag(kb, ld, 16 * kt, ks, S, lane);
-      vf[ks] = gfrag(vb, ld, 16 * kt, ks, S, lane);
+      kf[ks] = lfrag_row<HE>(lk, 16 * kt, ks, lane);
+      vf[ks] = lfrag_row<HE>(lv, 16 * kt, ks, lane);
     }
     f32x4 pr[NT], ds[NT];
 #pragma unroll
@@ -256,17 +298,18 @@ __global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __r
       f32x4 s = zero, dp = zero;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = vg_mfma(lfrag_row<HE>(l0, 16 * qt, ks, lane), kf[ks], s);
-        dp = vg_mfma(lfrag_row<HE>(l1, 16 * qt, ks, lane), vf[ks], dp);
+        s = vg_mfma(lfrag_row<HE>(lq, 16 * qt, ks, lane), kf[ks], s);
+        dp = vg_mfma(lfrag_row<HE>(ldo, 16 * qt, ks, lane), vf[ks], dp);
       }
+      const f32x4 lq4 = *(const f32x4*)(ll + 16 * qt + 4 * g);
+      const f32x4 dl4 = *(const f32x4*)(dl + 16 * qt + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = 16 * qt + 4 * g + r;
         const bool ok = (q < S) && (key < S);
-        const float lq = (q < S) ? lb[q] : 0.f;
-        const float p = ok ? __expf(s[r] * scale - lq) : 0.f;
+        const float p = ok ? __expf(s[r] * scale - lq4[r]) : 0.f;
         pr[qt][r] = p;
-        ds[qt][r] = p * (dp[r] - dl[q]) * scale;
+        ds[qt][r] = p * (dp[r] - dl4[r]) * scale;
       }
     }
     f32x4 dv[DT], dk[DT];
@@ -279,34 +322,36 @@ __global__ __launch_bounds__(64 * NT, 4) void vg_attn_bwd_kernel(const bf16* __r
       const bf16x8 dsf = pack_pair(ds[2 * u], (2 * u + 1 < NT) ? ds[hi] : zero);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        dv[dt] = vg_mfma(lfrag_tr<HE>(l1, u, 16 * dt, lane), pf, dv[dt]);
-        dk[dt] = vg_mfma(lfrag_tr<HE>(l0, u, 16 * dt, lane), dsf, dk[dt]);
+        dv[dt] = vg_mfma(lfrag_tr<HE>(ldo, u, 16 * dt, lane), pf, dv[dt]);
+        dk[dt] = vg_mfma(lfrag_tr<HE>(lq, u, 16 * dt, lane), dsf, dk[dt]);
       }
     }
-    if (key < S) {
-      bf16* pk = dqb + (size_t)key * ld + E + 4 * g;
-      bf16* pv = dqb + (size_t)key * ld + 2 * E + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        bf16x4 wk, wv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { wk[r] = vg_f2bf(dk[dt][r]); wv[r] = vg_f2bf(dv[dt][r]); }
-        *(bf16x4*)(pk + 16 * dt) = wk;
-        *(bf16x4*)(pv + 16 * dt) = wv;
-      }
-    }
+    bf16* rowp = dqb + (size_t)(key < S ? key : 0) * ld;
+    store_tiles<DT>(rowp + E, dk, 1.0f, g, key < S);
+    store_tiles<DT>(rowp + 2 * E, dv, 1.0f, g, key < S);
   }
+}
+
+__device__ __attribute__((aligned(16))) unsigned int vg_attn_zero_page[4] = {0u, 0u, 0u, 0u};
+static const void* attn_zeros() {
+  static void* zp = nullptr;  // one device per process
+  if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(vg_attn_zero_page)) != hipSuccess) zp = nullptr;
+  return zp;
 }
 
 template <int HE, int NT>
 static int launch_fwd(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale);
+  const void* z = attn_zeros();
+  if (!z) return -5;
+  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
   return (int)hipGetLastError();
 }
 template <int HE, int NT>
 static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
                       int S, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale);
+  const void* z = attn_zeros();
+  if (!z) return -5;
+  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
   return (int)hipGetLastError();
 }
 

@@ -22,17 +22,29 @@
 
 #define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
-#define BK 32
+#define BK 32           // k per MFMA sub-step
+#ifndef VG_BKS
+#define VG_BKS 1        // MFMA sub-steps per LDS stage: a stage holds BKS = 32 * VG_BKS of k
+#endif
+#define BKS (BK * VG_BKS)
+#ifndef VG_ABLATE
+#define VG_ABLATE 0
+#endif
 #ifndef NSTAGE_WM2
 #define NSTAGE_WM2 2
 #endif
+#ifndef NSTAGE_WM4
 #define NSTAGE_WM4 3
+#endif
+#ifndef OCC_WM4
+#define OCC_WM4 4
+#endif
 #define NSTAGE (WM == 2 ? NSTAGE_WM2 : NSTAGE_WM4)   // LDS ring: NSTAGE-1 k-steps in flight + 1 being read
 #ifndef OCC_WM2
 #define OCC_WM2 4
 #endif
-#define A_TILE_BYTES (BM * BK * 2)
-#define B_TILE_BYTES 8192
+#define A_TILE_BYTES (BM * BKS * 2)
+#define B_TILE_BYTES (BN * BKS * 2)
 #define STAGE_BYTES (A_TILE_BYTES + B_TILE_BYTES)
 
 __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
@@ -45,7 +57,12 @@ __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ int row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }  // {0,2,3,1}
+// row-form chunk swizzle.  64-B rows (VG_BKS 1): {0,2,3,1}[(r>>2)&3]; 128-B rows (VG_BKS 2): (r>>1)&7 - the 16 lanes
+// of a ds_read_b128 group then cover (row parity, chunk) = all 16 slots of a 256-B bank row.
+__device__ __forceinline__ int row_f(int r) {
+  if (VG_BKS == 1) return (0x78 >> (2 * ((r >> 2) & 3))) & 3;
+  return (r >> 1) & 7;
+}
 
 // PIECES 1-KiB pieces per tile (8 per 128 rows/cols), dealt round-robin to the NW waves.
 // The per-lane source pointer of every piece is computed ONCE per tile (`setup`); a k-step then only
@@ -62,13 +79,14 @@ struct Stager {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int j = wid + NW * i;
-      if (!TR) {  // piece = 16 rows x 64 B
-        const int rl = 16 * j + (lane >> 2);
+      if (!TR) {  // piece = 16 rows x 64 B (VG_BKS 1) or 8 rows x 128 B = whole cache lines (VG_BKS 2)
+        constexpr int LPR = 4 * VG_BKS;  // lanes (16-B chunks) per row
+        const int rl = (64 / LPR) * j + lane / LPR;
         const int row = idx0 + rl;
-        kc[i] = ((lane & 3) ^ row_f(rl)) << 3;
+        kc[i] = ((lane & (LPR - 1)) ^ row_f(rl)) << 3;
         src[i] = (row < idx_end) ? X + (size_t)row * ld + kc[i] : nullptr;
-      } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 pieces per sub-tile)
-        const int sub = j >> 3, jj = j & 7;
+      } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 * VG_BKS pieces per sub-tile)
+        const int sub = j / (8 * VG_BKS), jj = j % (8 * VG_BKS);
         const int kk = 4 * jj + (lane >> 4);
         const int c = (lane & 15) ^ (2 * tr_sigma(kk));
         const int col = idx0 + 128 * sub + (c << 3);
@@ -89,17 +107,17 @@ struct Stager {
 
 // ---- LDS -> MFMA fragment: 16 rows/cols starting at i0, k sub-step ks (32 wide) -------------
 template <bool TR>
-__device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, int lane) {
+__device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, int lane, int ks) {
   const int g = lane >> 4, li = lane & 15;
   if (!TR) {
     const int row = i0 + li;
-    return *(const bf16x8*)(tile + row * 64 + ((g ^ row_f(row)) << 4));
+    return *(const bf16x8*)(tile + row * (64 * VG_BKS) + (((4 * ks + g) ^ row_f(row)) << 4));
   } else {
     const int q = li >> 2, p = li & 3;
     const int c8 = ((i0 & 127) >> 2) + p;
     const int sw = 2 * (q | ((g & 1) << 2));
     const int kk0 = 8 * g + q;
-    const unsigned char* a0 = tile + (i0 >> 7) * 8192 + kk0 * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);
+    const unsigned char* a0 = tile + (i0 >> 7) * (8192 * VG_BKS) + (32 * ks + kk0) * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);
     typedef bf16x4 __attribute__((address_space(3))) * lds4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + 4 * 256));
@@ -126,7 +144,7 @@ enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31, 
 // 8-12 waves/CU by 25-40 %): WM=2 -> 2-stage ring (32 KiB) x 4 workgroups/CU, WM=4 -> 3-stage ring (72 KiB) x 2
 // workgroups/CU; both 4 waves/SIMD, so at most 128 registers per lane.
 template <int MODE, int WM, int ACT, int FEAT>
-__global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_kernel(const VgGemmGroup grp) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_gemm_kernel(const VgGemmGroup grp) {
   constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);
@@ -191,15 +209,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
 #else
 #define STAMP(i)
 #endif
-  const int nsteps = (k_end - k_begin + BK - 1) / BK;
-  Stager<A_TR, 4 * WM, NW> sa;
-  Stager<B_TR, 8, NW> sb;
+  const int nsteps = (k_end - k_begin + BKS - 1) / BKS;
+  Stager<A_TR, 4 * WM * VG_BKS, NW> sa;
+  Stager<B_TR, 8 * VG_BKS, NW> sb;
   sa.setup(Ag, lda, m0, P.M, wid, lane);
   sb.setup(Bg, ldb, n0, P.N, wid, lane);
 #define ISSUE(step)                                                                                      \
   do {                                                                                                   \
     unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
-    const int _k0 = k_begin + (step) * BK;                                                               \
+    const int _k0 = k_begin + (step) * BKS;                                                              \
     sa.issue(_b, _k0, k_end, zeros, wid);                                                                \
     sb.issue(_b + A_TILE_BYTES, _k0, k_end, zeros, wid);                                                 \
   } while (0)
@@ -207,51 +225,46 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : 4)) void vg_gemm_ker
   // ds_read fragments -> 16 MFMAs.  With 2 workgroups per CU the other workgroup's waves fill the
   // SIMD while this one waits.  (A register-double-buffered variant that read step s+1's fragments
   // under step s's MFMAs measured no faster on MI355X - LDS bandwidth, not latency, is the co-limit.)
-  constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
+  constexpr int DPS = (4 * WM + 8) * VG_BKS / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4), x VG_BKS
   STAMP(1);
   for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
   STAMP(2);
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     const int ahead = nsteps - 1 - s;  // stages issued after s (at most NSTAGE-2 of them are in flight here)
-    if (NSTAGE >= 4 && ahead >= 2) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); }
-    else if (NSTAGE >= 3 && ahead >= 1) { if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
+    if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * DPS) : "memory");
+    else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef VG_STAMPS
     if (s == 0) STAMP(3);
 #endif
-#ifdef VG_STAMPS
-    const int dbg = grp.dbg;
+    constexpr int dbg = VG_ABLATE;  // timing experiments only (make abl): 1 = no DMA, 2 = no LDS reads, 4 = no MFMA
     if (s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
-#else
-    if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1);
-#endif
     const unsigned char* cur = smem + (s % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < VG_BKS; ++ks) {
     bf16x8 fm[4], fn[4];
-#ifdef VG_STAMPS
     if (dbg & 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { for (int j = 0; j < 8; ++j) { fm[i][j] = (bf16)(float)(s + i); fn[i][j] = (bf16)(float)(lane + i); } }
     } else
-#endif
     {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane);
-        fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane);
+        fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane, ks);
+        fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane, ks);
       }
     }
-#ifdef VG_STAMPS
     if (dbg & 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)fm[i][0]; acc[0][i][1] += (float)fn[i][1]; }
     } else
-#endif
     {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
+    }
     }
   }
 #undef ISSUE
@@ -426,7 +439,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   grp.n = n;
 #ifdef VG_STAMPS
   grp.stamps = getenv("VG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("VG_STAMP_PTR"), nullptr, 0) : nullptr;
-  grp.dbg = getenv("VG_GEMM_DBG") ? atoi(getenv("VG_GEMM_DBG")) : 0;
+
 #endif
   {
     static void* zp = nullptr;  // one device per process (one process per GPU)
@@ -447,9 +460,9 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + BN - 1) / BN;
     int splits = (mode == VG_TN) ? (p.splits > 0 ? p.splits : 1) : 1;
-    int ksteps = (p.K + BK - 1) / BK;
+    int ksteps = (p.K + BKS - 1) / BKS;
     int per = (ksteps + splits - 1) / splits;
-    p.k_per_split = per * BK;
+    p.k_per_split = per * BKS;
     splits = (ksteps + per - 1) / per;  // drop empty slices
     p.splits = splits;
     if (dbg_nostore && mode != VG_TN) { p.C = nullptr; p.C2 = nullptr; p.pre_f32 = 0; }
