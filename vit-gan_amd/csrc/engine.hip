@@ -409,7 +409,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     {
       // the four weight gradients of the block as ONE grouped split-K launch
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
-      const int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
+      static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;  // tuning aid
+      const int splits = (split_env > 0 && split_env <= VIT_SPLIT_CAP) ? split_env : pick_splits(tiles, M, VIT_SPLIT_CAP);  // slab holds CAP slices
       VgGemmProb pr[4];
       pr[0] = wg(cur.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);

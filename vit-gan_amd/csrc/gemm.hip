@@ -23,6 +23,9 @@
 #define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
 #define BK 32           // k per MFMA sub-step
+#ifndef VG_ISSUE_LATE
+#define VG_ISSUE_LATE 0   // 1: issue the next stage's DMA after this step's fragment reads (only useful with VG_ASM_READS 0)
+#endif
 #ifndef VG_BKS
 #define VG_BKS 1        // MFMA sub-steps per LDS stage: a stage holds BKS = 32 * VG_BKS of k
 #endif
@@ -39,7 +42,10 @@
 #ifndef OCC_WM4
 #define OCC_WM4 4
 #endif
-#define NSTAGE (WM == 2 ? NSTAGE_WM2 : NSTAGE_WM4)   // LDS ring: NSTAGE-1 k-steps in flight + 1 being read
+#ifndef NSTAGE_TN
+#define NSTAGE_TN 3      // weight gradients: long k loops at 2-3 workgroups per CU - a deeper ring instead of occupancy
+#endif
+#define NSTAGE (MODE == VG_TN ? NSTAGE_TN : (WM == 2 ? NSTAGE_WM2 : NSTAGE_WM4))   // LDS ring: NSTAGE-1 k-steps in flight + 1 being read
 #ifndef OCC_WM2
 #define OCC_WM2 4
 #endif
@@ -53,7 +59,6 @@ __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) 
 // The LDS destination of one instruction is wave-uniform base + lane*16, so the tile images are
 // lane-linear per 1-KiB piece and the XOR swizzle is applied to the per-lane SOURCE address
 // (cdna_hip_programming.md rule 21).  A tile is 16 pieces; wave w issues pieces w, w+4, w+8, w+12.
-// Out-of-range lanes read 16 zero bytes from `zeros` instead (keeps the LDS image finite).
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -65,43 +70,68 @@ __device__ __forceinline__ int row_f(int r) {
 }
 
 // PIECES 1-KiB pieces per tile (8 per 128 rows/cols), dealt round-robin to the NW waves.
-// The per-lane source pointer of every piece is computed ONCE per tile (`setup`); a k-step then only
-// advances it, so issuing a piece costs a couple of VALU ops next to the DMA instruction itself.
+// Addressing is split into a wave-UNIFORM base (tile origin at the current k, kept in SGPRs and advanced by one
+// scalar add per k-step) and a per-lane 32-bit byte offset per piece that never changes: in the steady state a
+// piece costs its DMA instruction and nothing else.  Lanes whose row / column lies beyond the matrix are CLAMPED
+// onto its last row / 8-column group: what they fetch only reaches accumulator rows / columns the epilogue never
+// stores.  Only a k tail (k_end not a multiple of the stage depth: patch-embed K = 48, ragged wgrad splits) needs
+// real zeros; that one step takes the per-lane select path (`issue_tail`, 16 zero bytes from `zeros`).
 template <bool TR, int PIECES, int NW>
 struct Stager {
   static constexpr int PER = PIECES / NW;
-  const bf16* src[PER];   // per-lane pointer at k = 0 of this tile, nullptr when the lane's row/column is out of range
-  int kc[PER];            // row form: lane's k offset inside a step (elements); tr form: lane's k row inside a step
-  long long kstride;      // elements to advance per unit of k (1 for row form, ld for tr form)
+  const char* base;       // uniform: &X[k_cur * kstride] as bytes (row form: + k_cur elements; tr form: + k_cur rows)
+  long long step_bytes;   // uniform: bytes per k-step
+  unsigned voff[PER];     // per lane: byte offset of its 16-B chunk of piece i from `base`
+  int k_cur;              // uniform: k of the next stage to issue
 
-  __device__ __forceinline__ void setup(const bf16* __restrict__ X, int ld, int idx0, int idx_end, int wid, int lane) {
-    kstride = TR ? ld : 1;
+  // k offset (elements) of this lane's chunk inside a stage, piece j
+  static __device__ __forceinline__ int lane_k(int j, int lane) {
+    if (!TR) {
+      constexpr int LPR = 4 * VG_BKS;
+      const int rl = (64 / LPR) * j + lane / LPR;
+      return ((lane & (LPR - 1)) ^ row_f(rl)) << 3;
+    }
+    return 4 * (j % (8 * VG_BKS)) + (lane >> 4);
+  }
+  __device__ __forceinline__ void setup(const bf16* __restrict__ X, int ld, int idx0, int idx_end, int k_begin, int wid, int lane) {
+    base = (const char*)(X + (size_t)k_begin * (TR ? ld : 1));
+    step_bytes = (long long)BKS * (TR ? ld : 1) * 2;
+    k_cur = k_begin;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int j = wid + NW * i;
       if (!TR) {  // piece = 16 rows x 64 B (VG_BKS 1) or 8 rows x 128 B = whole cache lines (VG_BKS 2)
         constexpr int LPR = 4 * VG_BKS;  // lanes (16-B chunks) per row
         const int rl = (64 / LPR) * j + lane / LPR;
-        const int row = idx0 + rl;
-        kc[i] = ((lane & (LPR - 1)) ^ row_f(rl)) << 3;
-        src[i] = (row < idx_end) ? X + (size_t)row * ld + kc[i] : nullptr;
+        const int row = min(idx0 + rl, idx_end - 1);
+        voff[i] = ((unsigned)row * (unsigned)ld + (unsigned)lane_k(j, lane)) * 2u;
       } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 * VG_BKS pieces per sub-tile)
-        const int sub = j / (8 * VG_BKS), jj = j % (8 * VG_BKS);
-        const int kk = 4 * jj + (lane >> 4);
+        const int sub = j / (8 * VG_BKS);
+        const int kk = lane_k(j, lane);
         const int c = (lane & 15) ^ (2 * tr_sigma(kk));
-        const int col = idx0 + 128 * sub + (c << 3);
-        kc[i] = kk;
-        src[i] = (col < idx_end) ? X + (size_t)kk * ld + col : nullptr;
+        const int col = min(idx0 + 128 * sub + (c << 3), idx_end - 8);
+        voff[i] = ((unsigned)kk * (unsigned)ld + (unsigned)col) * 2u;
       }
     }
   }
-  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int k_end, const void* zeros, int wid) const {
+  // full stage (k_cur + BKS <= k_end)
+  __device__ __forceinline__ void issue(unsigned char* tile, int wid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[i]), (lptr_t)(tile + 1024 * (wid + NW * i)), 16, 0, 0);
+    base += step_bytes;
+    k_cur += BKS;
+  }
+  // last, partial stage: chunks at k >= k_end come from the zero page
+  __device__ __forceinline__ void issue_tail(unsigned char* tile, int k_end, const void* zeros, int wid, int lane) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int j = wid + NW * i;
-      const void* p = (src[i] != nullptr && k0 + kc[i] < k_end) ? (const void*)(src[i] + (long long)k0 * kstride) : zeros;
+      const void* p = (k_cur + lane_k(j, lane) < k_end) ? (const void*)(base + voff[i]) : zeros;
       __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(tile + 1024 * j), 16, 0, 0);
     }
+    base += step_bytes;
+    k_cur += BKS;
   }
 };
 
@@ -125,6 +155,72 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, i
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
+  }
+}
+
+// ---- the same fragments by inline asm (VG_BKS == 1) -----------------------------------------------------
+// The compiler cannot tell an LDS-DMA's destination stage from the stage being read and puts `s_waitcnt vmcnt(0)`
+// in front of every ds_read that follows a global_load_lds - which drains the whole prefetch ring at every k-step
+// (a deeper ring then buys nothing).  Reads issued from inline asm carry no such dependence; the counted
+// `s_waitcnt vmcnt(N)` + `s_barrier` at the top of the step is the only synchronisation, as intended.
+// One asm block per step: all ds_reads of both operands, then s_waitcnt lgkmcnt(0).
+#ifndef VG_ASM_READS
+#define VG_ASM_READS (VG_BKS == 1)
+#endif
+// loop-invariant LDS byte offsets (inside a stage) of a wave's fragments
+template <bool TR>
+struct FragAddr {
+  unsigned a[TR ? 4 : 1];
+  __device__ __forceinline__ void setup(int tile_off, int w0, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    if (!TR) {
+      a[0] = tile_off + (w0 + li) * 64 + ((g ^ row_f(w0 + li)) << 4);   // fragment i at + 1024 * i
+    } else {
+      const int q = li >> 2, p = li & 3, sw = 2 * (q | ((g & 1) << 2)), kk0 = 8 * g + q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int i0 = w0 + 16 * i, c8 = ((i0 & 127) >> 2) + p;
+        a[i] = tile_off + (i0 >> 7) * 8192 + kk0 * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);  // hi half at + 1024
+      }
+    }
+  }
+};
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 as_frag(u32x2 lo, u32x2 hi) { return __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]}); }
+
+#define VG_RD128_4(o0, o1, o2, o3, ad) \
+  "ds_read_b128 %" #o0 ", %" #ad "\n\tds_read_b128 %" #o1 ", %" #ad " offset:1024\n\t" \
+  "ds_read_b128 %" #o2 ", %" #ad " offset:2048\n\tds_read_b128 %" #o3 ", %" #ad " offset:3072\n\t"
+#define VG_RDTR_2(o0, o1, ad) "ds_read_b64_tr_b16 %" #o0 ", %" #ad "\n\tds_read_b64_tr_b16 %" #o1 ", %" #ad " offset:1024\n\t"
+
+template <bool A_TR, bool B_TR>
+__device__ __forceinline__ void load_frags_asm(unsigned sb, const FragAddr<A_TR>& fa, const FragAddr<B_TR>& fb, bf16x8 (&fm)[4], bf16x8 (&fn)[4]) {
+  if constexpr (!A_TR && !B_TR) {
+    u32x4 m0, m1, m2, m3, n0, n1, n2, n3;
+    asm volatile(VG_RD128_4(0, 1, 2, 3, 8) VG_RD128_4(4, 5, 6, 7, 9) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+                 : "v"(sb + fa.a[0]), "v"(sb + fb.a[0]) : "memory");
+    fm[0] = as_frag(m0); fm[1] = as_frag(m1); fm[2] = as_frag(m2); fm[3] = as_frag(m3);
+    fn[0] = as_frag(n0); fn[1] = as_frag(n1); fn[2] = as_frag(n2); fn[3] = as_frag(n3);
+  } else if constexpr (!A_TR && B_TR) {
+    u32x4 m0, m1, m2, m3;
+    u32x2 l0, h0, l1, h1, l2, h2, l3, h3;
+    asm volatile(VG_RD128_4(0, 1, 2, 3, 12) VG_RDTR_2(4, 5, 13) VG_RDTR_2(6, 7, 14) VG_RDTR_2(8, 9, 15) VG_RDTR_2(10, 11, 16) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                 : "v"(sb + fa.a[0]), "v"(sb + fb.a[0]), "v"(sb + fb.a[1]), "v"(sb + fb.a[2]), "v"(sb + fb.a[3]) : "memory");
+    fm[0] = as_frag(m0); fm[1] = as_frag(m1); fm[2] = as_frag(m2); fm[3] = as_frag(m3);
+    fn[0] = as_frag(l0, h0); fn[1] = as_frag(l1, h1); fn[2] = as_frag(l2, h2); fn[3] = as_frag(l3, h3);
+  } else {
+    static_assert(A_TR && B_TR, "operand forms: NT, NN, TN");
+    u32x2 al0, ah0, al1, ah1, al2, ah2, al3, ah3, l0, h0, l1, h1, l2, h2, l3, h3;
+    asm volatile(VG_RDTR_2(0, 1, 16) VG_RDTR_2(2, 3, 17) VG_RDTR_2(4, 5, 18) VG_RDTR_2(6, 7, 19)
+                 VG_RDTR_2(8, 9, 20) VG_RDTR_2(10, 11, 21) VG_RDTR_2(12, 13, 22) VG_RDTR_2(14, 15, 23) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(al0), "=&v"(ah0), "=&v"(al1), "=&v"(ah1), "=&v"(al2), "=&v"(ah2), "=&v"(al3), "=&v"(ah3),
+                   "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                 : "v"(sb + fa.a[0]), "v"(sb + fa.a[1]), "v"(sb + fa.a[2]), "v"(sb + fa.a[3]),
+                   "v"(sb + fb.a[0]), "v"(sb + fb.a[1]), "v"(sb + fb.a[2]), "v"(sb + fb.a[3]) : "memory");
+    fm[0] = as_frag(al0, ah0); fm[1] = as_frag(al1, ah1); fm[2] = as_frag(al2, ah2); fm[3] = as_frag(al3, ah3);
+    fn[0] = as_frag(l0, h0); fn[1] = as_frag(l1, h1); fn[2] = as_frag(l2, h2); fn[3] = as_frag(l3, h3);
   }
 }
 
@@ -187,7 +283,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_ge
   const int k_begin = split * P.k_per_split;
   const int k_end = min(P.K, k_begin + P.k_per_split);
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: per-wave LDS bases stay in SGPRs
   const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
   const int g = lane >> 4, li = lane & 15;
 
@@ -212,19 +309,31 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_ge
   const int nsteps = (k_end - k_begin + BKS - 1) / BKS;
   Stager<A_TR, 4 * WM * VG_BKS, NW> sa;
   Stager<B_TR, 8 * VG_BKS, NW> sb;
-  sa.setup(Ag, lda, m0, P.M, wid, lane);
-  sb.setup(Bg, ldb, n0, P.N, wid, lane);
+  sa.setup(Ag, lda, m0, P.M, k_begin, wid, lane);
+  sb.setup(Bg, ldb, n0, P.N, k_begin, wid, lane);
+  // stages are issued strictly in order (prologue, then one per k-step), so the stagers keep a running k
 #define ISSUE(step)                                                                                      \
   do {                                                                                                   \
     unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
-    const int _k0 = k_begin + (step) * BKS;                                                              \
-    sa.issue(_b, _k0, k_end, zeros, wid);                                                                \
-    sb.issue(_b + A_TILE_BYTES, _k0, k_end, zeros, wid);                                                 \
+    if (sa.k_cur + BKS <= k_end) {                                                                       \
+      sa.issue(_b, wid);                                                                                 \
+      sb.issue(_b + A_TILE_BYTES, wid);                                                                  \
+    } else {                                                                                             \
+      sa.issue_tail(_b, k_end, zeros, wid, lane);                                                        \
+      sb.issue_tail(_b + A_TILE_BYTES, k_end, zeros, wid, lane);                                         \
+    }                                                                                                    \
   } while (0)
   // Per k-step: counted vmcnt (stage s landed; s+1, s+2 may still fly) -> s_barrier -> DMA for s+3 ->
   // ds_read fragments -> 16 MFMAs.  With 2 workgroups per CU the other workgroup's waves fill the
   // SIMD while this one waits.  (A register-double-buffered variant that read step s+1's fragments
   // under step s's MFMAs measured no faster on MI355X - LDS bandwidth, not latency, is the co-limit.)
+#if VG_ASM_READS
+  const unsigned smem_base = (unsigned)(unsigned long)(lptr_t)smem;
+  FragAddr<A_TR> fra;
+  FragAddr<B_TR> frb;
+  fra.setup(0, wm * 64, lane);
+  frb.setup(A_TILE_BYTES, wn * 64, lane);
+#endif
   constexpr int DPS = (4 * WM + 8) * VG_BKS / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4), x VG_BKS
   STAMP(1);
   for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
@@ -239,7 +348,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_ge
     if (s == 0) STAMP(3);
 #endif
     constexpr int dbg = VG_ABLATE;  // timing experiments only (make abl): 1 = no DMA, 2 = no LDS reads, 4 = no MFMA
+#if !VG_ISSUE_LATE
     if (s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
+#endif
     const unsigned char* cur = smem + (s % NSTAGE) * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < VG_BKS; ++ks) {
@@ -249,12 +360,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_ge
       for (int i = 0; i < 4; ++i) { for (int j = 0; j < 8; ++j) { fm[i][j] = (bf16)(float)(s + i); fn[i][j] = (bf16)(float)(lane + i); } }
     } else
     {
+#if VG_ASM_READS
+      load_frags_asm<A_TR, B_TR>(smem_base + (s % NSTAGE) * STAGE_BYTES, fra, frb, fm, fn);
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane, ks);
         fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane, ks);
       }
+#endif
     }
+#if VG_ISSUE_LATE
+    // The compiler cannot tell the LDS-DMA's destination from the stage being read and puts s_waitcnt vmcnt(0) in
+    // front of the first ds_read that follows a DMA in program order: issuing the next stage AFTER this step's
+    // fragment reads keeps that wait from draining the prefetch (it then lands under this step's MFMAs).
+    if (ks == VG_BKS - 1 && s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
+#endif
     if (dbg & 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)fm[i][0]; acc[0][i][1] += (float)fn[i][1]; }
@@ -430,7 +551,8 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   int wm4 = 1;
   for (int i = 0; i < n; ++i) {
     const long long t4 = (long long)((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
-    if (t4 < 512 || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
+    static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;  // tuning aid
+    if (t4 < t4min || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
   }
   if (const char* e = getenv("VG_GEMM_WM")) wm4 = (atoi(e) == 4) && mode != VG_TN;
   const int bm = wm4 ? 256 : 128;
