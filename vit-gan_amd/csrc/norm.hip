@@ -145,6 +145,15 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
     const float mu = mean[rr], rs = rstd[rr];
     float xh[NV][CH], gg[NV][CH];
     float c1 = 0.f, c2 = 0.f;
+    // the residual-stream gradient is only needed after the row reduction: fetch it now, with x and dy, so one
+    // memory round trip per row instead of two
+    typename ChunkT<CH>::bt rraw[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) rraw[i][j] = (bf16)0.f;
+      if (gres && ok) rraw[i] = *(const typename ChunkT<CH>::bt*)(gres + (size_t)rr * E + CH * (sub + LPR * i));
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = CH * (sub + LPR * i);
@@ -187,13 +196,11 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = CH * (sub + LPR * i);
-      float rv[CH];
-      if (gres) ld_chunk<CH>(gres + (size_t)rr * E + c, ok, rv);
       typename ChunkT<CH>::bt o;
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         float t = rs * (gg[i][j] - c1 - xh[i][j] * c2);
-        if (gres) t += rv[j];
+        if (gres) t += vg_bf2f(rraw[i][j]);
         o[j] = vg_f2bf(t);
       }
       if (ok) *(typename ChunkT<CH>::bt*)(dx + (size_t)rr * E + c) = o;
