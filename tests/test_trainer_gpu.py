@@ -1,0 +1,49 @@
+"""train_model end to end on the GPU: artefacts of the reference's trainer shell."""
+import glob
+import os
+import re
+
+import pytest
+import torch
+
+import vit_gan_amd  # noqa: F401
+from vit_gan_amd.config import Config
+from vit_gan_amd.generator import SirenGenerator
+from vit_gan_amd.modules import ViTDiscriminator
+from vit_gan_amd.training import TrainedGan, train_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_model_writes_the_reference_artefacts(tmp_path):
+    cfg = {"epochs": 2, "batch_size": 16, "embeddings_dimension": 128, "attention_heads_count": 4, "transformer_blocks_count": 2}
+    fids = iter([30.7, 12.2])
+    out = train_model(cfg, steps_per_epoch=3, output_base=str(tmp_path), fid_fn=lambda gan, epoch: next(fids))
+    d = out["dirs"]
+    assert len(out["history"]) == 2 and all(torch.isfinite(torch.tensor(h)).all() for h in out["history"])
+    for e in (0, 1):
+        for sub, stem in ((d.images, "samples"), (d.noise, "noise"), (d.input, "input")):
+            assert os.path.getsize(os.path.join(sub, f"{stem}_epoch_{e}.png")) > 100
+    assert sorted(os.path.basename(p) for p in glob.glob(os.path.join(d.checkpoints, "*.pth"))) == [
+        "best_model_epoch_0_fid_30.pth", "best_model_epoch_1_fid_12.pth"]
+    text = open(os.path.join(d.save, "training.log")).read()
+    assert "Starting training at:" in text and "Parameters:" in text and "Run took" in text
+    lines = re.findall(r"Epoch \[(\d)/2\] \| Disc Loss: [-\d.]+, Gen Loss: [-\d.]+ \| FID: ([\d.]+)", text)
+    assert lines == [("0", "30.7000"), ("1", "12.2000")]
+    # the final checkpoint loads strict=True into freshly built modules and reproduces the trained weights
+    state = torch.load(os.path.join(d.save, "final_model.ckpt"), map_location="cpu")
+    c = Config(**cfg).model_copy(update={"classes_count": 1})
+    fresh = TrainedGan(SirenGenerator(image_size=c.image_size, channels=c.input_channels), ViTDiscriminator(c))
+    fresh.load_state_dict(state, strict=True)
+    for k, v in out["gan"].state_dict().items():
+        assert torch.equal(v.cpu(), state[k]), k
+
+
+def test_exceptions_inside_the_loop_are_logged_not_raised(tmp_path):
+    def boom(gan, epoch):
+        raise ValueError("fid backend missing")
+    out = train_model({"epochs": 1, "batch_size": 8, "embeddings_dimension": 128, "transformer_blocks_count": 1},
+                      steps_per_epoch=1, output_base=str(tmp_path), fid_fn=boom)
+    text = open(os.path.join(out["dirs"].save, "training.log")).read()
+    assert "Exception: fid backend missing" in text and "Run took" in text
+    assert os.path.exists(os.path.join(out["dirs"].save, "final_model.ckpt"))
