@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 1
+#define VG_ABI_VERSION 2
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -170,8 +170,13 @@ int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dl
 
 /* v1 generator: mapping Linear -> L x TransformerSLN -> SLN -> SIREN x2 (src/v1/generator.py:58-69). */
 typedef struct VgGenDims {
-  int Z, T, E, H, L, O, CW; /* latent, tokens, embed, heads, layers, siren hidden, channels*image_w */
+  int Z, T, E, H, L, O, CW; /* latent, tokens, embed, heads, layers, siren hidden, output features per token */
   float omega0;
+  /* Token geometry.  patch == 0: the reference's v1 layout - one token per image ROW, CW = channels*image_w and the
+   * [B, T*CW] result IS the image through a flat view (generator.py:19,25,66-68).
+   * patch > 0: tokens on the discriminator's patch grid - T = (IH/patch)^2, CW = C*patch^2 in
+   * conv1's (c, py, px) order - and the image is assembled by the un-patchify scatter.  Not in the reference. */
+  int patch, C, IH;
 } VgGenDims;
 typedef struct VgGenLayout {
   long long emb, map_w, map_b;                  /* embedding [T,E], mapping Linear [T*E, Z], bias */
@@ -194,7 +199,7 @@ typedef struct VgGenNet {
   unsigned long long dropout_seed;
   const unsigned* dropout_step;
 } VgGenNet;
-/* z fp32 [B,Z]; img bf16 [B, T*CW] (== [B,C,IH,IW] flat view, generator.py:66-68). */
+/* z fp32 [B,Z]; img bf16 [B, T*CW]: the flat view of generator.py:66-68 (patch == 0) or NCHW [B,C,IH,IH] (patch > 0). */
 int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream);
 int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream);
 

@@ -31,6 +31,7 @@ class GenDims:
     channels: int = 3
     image: int = 32
     omega0: float = 30.0
+    patch: int = 0  # 0: reference layout (token = image row, flat view); > 0: patch-grid variant (unpinned)
 
     @property
     def head_dim(self) -> int:  # src/v1/transformer.py:54-57
@@ -38,7 +39,7 @@ class GenDims:
 
     @property
     def out_features(self) -> int:  # src/v1/generator.py:51
-        return self.channels * self.image
+        return self.channels * (self.patch * self.patch if self.patch else self.image)
 
 
 def gen_param_shapes(d: GenDims) -> Dict[str, tuple]:
@@ -138,6 +139,9 @@ def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Option
     y = sln(state, "sln.", h, w)  # (:65)
     y = siren(state, "output_network.0.", y, d.omega0)
     y = siren(state, "output_network.1.", y, d.omega0)  # [B, T, C*IW]
+    if d.patch:  # patch-grid variant: token t = (gy, gx) carries one C x P x P patch in (c, py, px) order
+        gh, P = d.image // d.patch, d.patch
+        return y.view(B, gh, gh, d.channels, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, d.channels, d.image, d.image)
     return y.view(B, d.channels, d.image, d.image)  # flat reinterpretation (:66-68)
 
 

@@ -206,3 +206,32 @@ def test_two_rank_data_parallel_engine_on_one_gpu():
     same, finite, differ = val
     assert same, "replicas diverged: weights / reduced gradients differ between ranks"
     assert finite and differ
+
+
+def test_engine_step_with_patch_grid_generator_at_c4_shape():
+    """SURVEY 8f row f1 + config C4's geometry (64x64, patch 8, 8 heads): patch-grid generator feeding the ViT
+    discriminator through GanEngine, against the fp32 step oracle (small widths so the CPU oracle stays in seconds)."""
+    import vit_gan_amd  # noqa: F401
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.engine import GanEngine
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator
+    from oracle import gen_oracle as go, step_oracle as so, vit_oracle as vo
+
+    B = 4
+    torch.manual_seed(5)
+    cfg = Config(embeddings_dimension=256, attention_heads_count=8, transformer_blocks_count=2, image_size=64, patch_size=8,
+                 classes_count=1, dropout_rate=0.0, batch_size=B)
+    D = ViTDiscriminator(cfg)
+    G = SirenGenerator(latent=256, image_size=64, channels=3, embed=256, heads=4, layers=2, siren_hidden=256, dropout=0.0, patch_size=8)
+    ddims = vo.VitDims(image=64, patch=8, embed=256, heads=8, layers=2, classes=1)
+    gdims = go.GenDims(latent=256, tokens=64, embed=256, heads=4, layers=2, siren_hidden=256, image=64, patch=8)
+    oracle = so.GanStepOracle({k: v.detach().clone() for k, v in D.state_dict().items()},
+                              {k: v.detach().clone() for k, v in G.state_dict().items()}, ddims, gdims)
+    eng = GanEngine(D.cuda(), G.cuda(), batch=B)
+    real = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    losses = eng.step(real.cuda())
+    torch.cuda.synchronize()
+    ref = oracle.step(real, eng.z.detach().cpu().clone())
+    got = losses.cpu().tolist()
+    assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)

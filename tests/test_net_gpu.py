@@ -100,7 +100,12 @@ def test_gen_forward_backward_vs_oracle(name):
     R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
     (out * R).sum().backward()
 
-    gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0)
+    gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0, 0, d.channels, d.image)
+    _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B)
+
+
+def _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B):
+    from vit_gan_amd import _lib, flat
     lay = flat.gen_layout(gd)
     slots = flat.gen_slots(gd)
     P = flat.pack(slots, lay.total, st_np, device="cuda")
@@ -125,3 +130,41 @@ def test_gen_forward_backward_vs_oracle(name):
         tol = 0.35 if k.endswith(("gamma", "beta")) else 0.12
         rel[k] = u.assert_close(grads[k], p.grad, tol, f"grad {k}", floor=1e-4)
     print("worst relative grad errors:", sorted(rel.items(), key=lambda kv: -kv[1])[:5])
+
+
+@pytest.mark.parametrize("image,patch,embed,heads,batch", [(32, 4, 384, 4, 3), (64, 8, 512, 8, 2), (128, 16, 256, 4, 1)])
+def test_patch_grid_generator_vs_oracle(image, patch, embed, heads, batch):
+    """the SLN/SIREN generator on the discriminator's patch grid (64 tokens, one C x P x P patch per
+    token, assembled by the un-patchify scatter).  Not in the reference - the oracle defines it ("parity unpinned")."""
+    import gpu_util as u
+    from weights import make_input
+    from oracle import gen_oracle as go
+    from vit_gan_amd import _lib
+
+    d = go.GenDims(latent=256, tokens=(image // patch) ** 2, embed=embed, heads=heads, layers=2, siren_hidden=256,
+                   channels=3, image=image, patch=patch)
+    st0 = go.init_gen_state(d, seed=11)
+    st_np = {k: v.numpy() for k, v in st0.items()}
+    st = {k: v.clone().requires_grad_(True) for k, v in st0.items()}
+    z = torch.from_numpy(make_input((batch, d.latent), 5))
+    out = go.gen_forward(st, z, d)
+    assert out.shape == (batch, 3, image, image)
+    R = torch.from_numpy(make_input(tuple(out.shape), 6))
+    (out * R).sum().backward()
+    gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0, patch, 3, image)
+    _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, batch)
+
+
+def test_patch_grid_generator_module_and_geometry_checks():
+    from vit_gan_amd import _lib, flat
+    from vit_gan_amd.generator import SirenGenerator
+    import ctypes as C_
+    G = SirenGenerator(latent=128, image_size=64, channels=3, embed=256, heads=4, layers=1, siren_hidden=128, dropout=0.0, patch_size=8).cuda()
+    assert G.embedding.shape == (64, 256) and G.output_network[1].linear.weight.shape == (3 * 64, 128)
+    img = G(torch.randn(2, 128, device="cuda"))
+    assert img.shape == (2, 3, 64, 64) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
+    img.sum().backward()
+    assert G.embedding.grad is not None and torch.isfinite(G.embedding.grad).all()
+    bad = _lib.VgGenDims(128, 60, 256, 4, 1, 128, 192, 30.0, 8, 3, 64)  # 60 tokens is not the 8x8 grid
+    lay = _lib.VgGenLayout()
+    assert _lib.lib().vg_gen_layout(C_.byref(bad), C_.byref(lay)) != 0

@@ -33,7 +33,8 @@ class VgVitNet(C.Structure):
 
 
 class VgGenDims(C.Structure):
-    _fields_ = [(n, c_int) for n in ("Z", "T", "E", "H", "L", "O", "CW")] + [("omega0", c_float)]
+    _fields_ = ([(n, c_int) for n in ("Z", "T", "E", "H", "L", "O", "CW")] + [("omega0", c_float)]
+                + [(n, c_int) for n in ("patch", "C", "IH")])
 
 
 class VgGenLayout(C.Structure):
@@ -110,7 +111,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.vg_abi_version() != 1:
+        if handle.vg_abi_version() != 2:
             raise RuntimeError("libvitgan_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -90,6 +90,12 @@ extern "C" int vg_gen_layout(const VgGenDims* d, VgGenLayout* o) {
   if (d->E % 128 || d->E % d->H || (d->Z & 7) || (d->O & 7) || (d->CW & 7) || d->T > 80 || d->L < 1) return -3;
   const int HE = d->E / d->H;
   if (HE != 32 && HE != 64 && HE != 96) return -3;
+  if (d->patch < 0) return -3;
+  if (d->patch > 0) {  // tokens on the patch grid: T and CW are determined by the image geometry
+    if (d->C < 1 || d->IH < d->patch || d->IH % d->patch) return -3;
+    const int gh = d->IH / d->patch;
+    if (d->T != gh * gh || d->CW != d->C * d->patch * d->patch) return -3;
+  }
   long long p = 0;
   o->emb = p; p = al64(p + T * E);
   o->map_w = p; p = al64(p + T * E * d->Z);
@@ -470,6 +476,7 @@ struct GenWs {
   bf16 *zb, *wmod, *s1, *qkv, *cat, *htmp, *s2, *hout, *sf, *y1;
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf, *zf1, *zf2;
   bf16 *g[3], *gm[2], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
+  bf16 *y2, *dy2;  // patch-grid variant only: token rows [R, CW] before the un-patchify / after the patchify of d_img
   float *dw_acc, *part, *part_cs, *emb_sum, *slab;
 };
 static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
@@ -500,6 +507,8 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.dcat = c.take<bf16>(R * E);
   w.dqkv = c.take<bf16>(R * 3 * E);
   w.dwb = c.take<bf16>(R * E);
+  w.y2 = c.take<bf16>(d.patch > 0 ? R * d.CW : 0);
+  w.dy2 = c.take<bf16>(d.patch > 0 ? R * d.CW : 0);
   w.dw_acc = c.take<float>(R * E);
   w.part = c.take<float>((2 * L + 1) * (long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));  // one block per SLN backward
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
@@ -563,7 +572,9 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
                            R, E, 1e-5f, st));
   VG_TRY(lin_fwd(w.sf, E, Pb + lay.s1_w, P + lay.s1_b, w.y1, R, d.O, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf1, st));
-  VG_TRY(lin_fwd(w.y1, d.O, Pb + lay.s2_w, P + lay.s2_b, (bf16*)img, R, d.CW, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf2, st));
+  bf16* rows = d.patch > 0 ? w.y2 : (bf16*)img;
+  VG_TRY(lin_fwd(w.y1, d.O, Pb + lay.s2_w, P + lay.s2_b, rows, R, d.CW, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf2, st));
+  if (d.patch > 0) VG_TRY(vg_unpatchify_launch(rows, (bf16*)img, B, d.C, d.IH, d.patch, st));  // token rows -> NCHW
   return 0;
 }
 
@@ -587,7 +598,12 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   bf16* const gm1buf = w.gm[1];  // gmid masked for the attention-branch dropout
 
   // SIREN output layers (siren.py:44-45): y = sin(w0 z)  ->  dz = dy * w0 cos(w0 z)
-  VG_TRY(vg_sin_grad_launch((const bf16*)d_img, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
+  const bf16* d_rows = (const bf16*)d_img;
+  if (d.patch > 0) {  // NCHW gradient -> token rows, the adjoint of the forward scatter
+    VG_TRY(vg_patchify_launch(d_img, 1, w.dy2, B, d.C, d.IH, d.patch, st));
+    d_rows = w.dy2;
+  }
+  VG_TRY(vg_sin_grad_launch(d_rows, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
   VG_TRY(vg_colsum_bf16_launch(w.dz2, d.CW, R, d.CW, w.part_cs, G + lay.s2_b, 1, st));
   {
     const int splits = pick_splits(tiles128(d.CW, d.O), R, GEN_SPLIT_CAP);

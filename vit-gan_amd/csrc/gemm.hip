@@ -240,7 +240,7 @@ enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31, 
 // 8-12 waves/CU by 25-40 %): WM=2 -> 2-stage ring (32 KiB) x 4 workgroups/CU, WM=4 -> 3-stage ring (72 KiB) x 2
 // workgroups/CU; both 4 waves/SIMD, so at most 128 registers per lane.
 template <int MODE, int WM, int ACT, int FEAT>
-__global__ __launch_bounds__(128 * WM, (WM == 2 ? OCC_WM2 : OCC_WM4)) void vg_gemm_kernel(const VgGemmGroup grp) {
+__global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 : OCC_WM4))) void vg_gemm_kernel(const VgGemmGroup grp) {
   constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);

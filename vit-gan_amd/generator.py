@@ -79,9 +79,21 @@ class _GenFn(torch.autograd.Function):
 
 class SirenGenerator(nn.Module):
     def __init__(self, latent=1024, image_size=32, channels=3, embed=384, heads=4, layers=4, siren_hidden=768,
-                 omega_0=30.0, out_dtype=torch.float32, dropout=0.2):
+                 omega_0=30.0, out_dtype=torch.float32, dropout=0.2, patch_size=0):
+        """``patch_size == 0`` (default): the reference's v1 generator - one token per image row, each emitting
+        ``channels * image_size`` values, assembled by a flat ``view`` (src/v1/generator.py:19,25,51,66-68).
+        ``patch_size > 0`` (not in the reference): the same blocks on the discriminator's patch
+        grid - ``(image_size / patch_size)**2`` tokens, each emitting one ``channels x P x P`` patch in conv1's
+        (c, py, px) order, assembled by the un-patchify scatter.  Scales to 64x64 / 128x128 images (64 tokens)."""
         super().__init__()
-        T, E, hd = image_size, embed, embed // heads
+        E, hd = embed, embed // heads
+        if patch_size:
+            if image_size % patch_size:
+                raise ValueError("image_size must be a multiple of patch_size")
+            T, out_features = (image_size // patch_size) ** 2, channels * patch_size * patch_size
+        else:
+            T, out_features = image_size, channels * image_size
+        self.patch_size = int(patch_size)
         self.latent, self.image_size, self.channels, self.out_dtype = latent, image_size, channels, out_dtype
         self.dropout_p = float(dropout)  # attention_dropout_rate = mlp_dropout = 0.2 in src/v1/config.py:36,39
         self.mapping_mlp = _mlp_holder(T * E, latent)
@@ -105,9 +117,10 @@ class SirenGenerator(nn.Module):
         self.sln = _sln_holder(E)
         s0, s1 = _Holder(), _Holder()
         s0.linear = _linear_holder(siren_hidden, E)
-        s1.linear = _linear_holder(channels * image_size, siren_hidden)
+        s1.linear = _linear_holder(out_features, siren_hidden)
         self.output_network = nn.Sequential(s0, s1)
-        self._dims = _lib.VgGenDims(latent, T, E, heads, layers, siren_hidden, channels * image_size, float(omega_0))
+        self._dims = _lib.VgGenDims(latent, T, E, heads, layers, siren_hidden, out_features, float(omega_0),
+                                    self.patch_size, channels, image_size)
         lay = flat.gen_layout(self._dims)
         self.reset_parameters()
         self._flat = FlatParams(dict(self.named_parameters()), flat.gen_slots(self._dims), lay.total)
