@@ -93,7 +93,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (C2: 256)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 256 for C2, 128 for C4 / C5)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 (default, the metric's configuration): 32x32 patch 4 E=384 4 heads, v1 row-token generator; "
+                         "c4: 64x64 patch 8 E=512 8 heads; c5: 128x128 patch 16 E=768 12 heads (bf16 attention) - "
+                         "both with the patch-grid generator (SURVEY 8f f1); extra measurements, not the headline")
     ap.add_argument("--loss", default="ns", choices=["ns", "hinge"])
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph; -1: auto (single GPU only)")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
@@ -107,7 +111,7 @@ def main():
         import vit_gan_amd  # noqa: F401
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
-        print(json.dumps({"roofline": gemm_roofline(torch, args.batch)}))
+        print(json.dumps({"roofline": gemm_roofline(torch, args.batch or 256)}))
         return
 
     import torch
@@ -132,17 +136,26 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
 
-    B = args.batch
+    geo = {"c2": dict(image=32, patch=4, embed=384, heads=4, batch=256, gpatch=0),
+           "c4": dict(image=64, patch=8, embed=512, heads=8, batch=128, gpatch=8),
+           "c5": dict(image=128, patch=16, embed=768, heads=12, batch=128, gpatch=16)}[args.workload]
+    B = args.batch or geo["batch"]
+    IMG = geo["image"]
     torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
-    cfg = Config(embeddings_dimension=384, attention_heads_count=4, transformer_blocks_count=6, mlp_ratio=2, patch_size=4,
-                 image_size=32, input_channels=3, classes_count=1, dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
+    cfg = Config(embeddings_dimension=geo["embed"], attention_heads_count=geo["heads"], transformer_blocks_count=6, mlp_ratio=2,
+                 patch_size=geo["patch"], image_size=IMG, input_channels=3, classes_count=1,
+                 dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
     D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
-    G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
+    if args.workload == "c2":
+        G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
+    else:
+        G = SirenGenerator(image_size=IMG, embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
+                           dropout=0.2 if args.dropout else 0.0).to(dev).train()
     use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                     concurrent_wgrad=not args.single_stream)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    reals = [torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
+    reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
 
     for i in range(args.warmup):
@@ -171,20 +184,26 @@ def main():
     ok = all(x == x and abs(x) < 1e4 for x in lv)
 
     if rank == 0:
-        f_d = vo.matmul_flops_per_image(vo.VitDims(classes=1))
-        f_g = go.matmul_flops_per_image(go.GenDims())
+        f_d = vo.matmul_flops_per_image(vo.VitDims(image=IMG, patch=geo["patch"], embed=geo["embed"], heads=geo["heads"], classes=1))
+        gd = G._dims
+        f_g = go.matmul_flops_per_image(go.GenDims(latent=gd.Z, tokens=gd.T, embed=gd.E, heads=gd.H, layers=gd.L, siren_hidden=gd.O,
+                                                    image=IMG, patch=geo["gpatch"]))
         f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
-        roof = gemm_roofline(torch, B)
+        roof = gemm_roofline(torch, 256 if args.workload != "c2" else B)  # the roofline leg always times the C2 shape
         roof["step_tflops_per_gpu"] = round(step_tf, 1)
         roof["step_frac_of_peak"] = round(step_tf / PEAK_BF16_TFLOPS, 4)
         out = {
-            "metric": "images/sec (G+D step) ViTGAN 32x32 patch4 dim384", "value": round(ips, 1), "unit": "images/sec",
+            "metric": "images/sec (G+D step) ViTGAN 32x32 patch4 dim384" if args.workload == "c2" else f"images/sec (G+D step) ViTGAN {args.workload} shape", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
-                                   "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
+            "config": {"workload": {"c2": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
+                                          "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
+                                    "c4": "C4 shape: 3x64x64, patch 8 (65 tokens), E=512, 8 heads, 6 blocks ViT discriminator + patch-grid "
+                                          "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW",
+                                    "c5": "C5 shape: 3x128x128, patch 16 (65 tokens), E=768, 12 heads, 6 blocks ViT discriminator + patch-grid "
+                                          "SLN/SIREN generator (64 tokens), bf16 attention, full alternating G+D step, AdamW"}[args.workload],
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
                        "parallelism": f"dp{world}", "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
