@@ -202,7 +202,7 @@ struct VitWs {
   // the weight-gradient side of block l still reads set l&1 while the main stream works on block l-1 in the other set
   struct Set { bf16 *gin, *gm2, *gmid, *gm1, *dz1, *dqkv; } set[2];
   float* lnpart;  // [2L] LayerNorm-backward partial-sum blocks, folded by one launch at the end of a backward call
-  float* cspart;  // [2L+1] bias-gradient partial blocks ([chunks][<=3E]), folded by the same launch
+  float* bslab;   // [L][VIT_SPLIT_CAP][3E + rE + E] bias-gradient rows written by the weight-gradient GEMM, one per K slice
   bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *tok_sum, *slab;
 };
@@ -233,7 +233,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
     t.dqkv = c.take<bf16>(M * 3 * E);
   }
   w.lnpart = c.take<float>(2 * L * (long long)vg_ln_bwd_nparts((int)M) * 3 * E);
-  w.cspart = c.take<float>((2 * L + 1) * (long long)vg_colsum_bf16_nparts((int)M) * 3 * E);
+  w.bslab = c.take<float>(L * (long long)VIT_SPLIT_CAP * (3 * E + (long long)d.R * E + E));
   w.dxn = c.take<bf16>(M * E);
   w.dao = c.take<bf16>(M * E);
   w.gp = c.take<bf16>(B * NP * E);
@@ -353,8 +353,6 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   int last_side = -1;  // highest-index side event recorded by this call (for the join)
   VgFoldJobs folds; folds.n = 0;
   const size_t part_sz = (size_t)lnparts * 3 * E;
-  const int cschunks = vg_colsum_bf16_nparts(M);
-  const size_t cs_sz = (size_t)cschunks * 3 * E;
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage < stage_begin) continue;
@@ -396,22 +394,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
-    if (l == top) {  // lower blocks get fc2's bias gradient from LN1's partials
-      float* pc = w.cspart + (size_t)(2 * d.L) * cs_sz;
-      VG_TRY(vg_colsum_bf16_part_launch(gb2, E, M, E, pc, sd));
-      vg_fold_push(folds, pc, cschunks, E, G + lo + lay.b2, E, nullptr, 0, nullptr, 0, nullptr, 0);
-    }
-    {
-      float* pc = w.cspart + (size_t)(2 * l) * cs_sz;
-      VG_TRY(vg_colsum_bf16_part_launch(cur.dz1, rE, M, rE, pc, sd));
-      vg_fold_push(folds, pc, cschunks, rE, G + lo + lay.b1, rE, nullptr, 0, nullptr, 0, nullptr, 0);
-    }
     vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0);
-    {
-      float* pc = w.cspart + (size_t)(2 * l + 1) * cs_sz;
-      VG_TRY(vg_colsum_bf16_part_launch(cur.dqkv, 3 * E, M, 3 * E, pc, sd));
-      vg_fold_push(folds, pc, cschunks, 3 * E, G + lo + lay.bqkv, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0);
-    }
     {
       // the four weight gradients of the block as ONE grouped split-K launch
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
@@ -422,8 +405,18 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
       pr[2] = wg(cur.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
       pr[3] = wg(gb2, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
+      // bias gradients = column sums of the same dY operands: they ride along in the GEMM (ones x A on the MFMA pipe),
+      // one row per K slice, folded with the LayerNorm partials at the end.  fc2's bias: only the top block needs it
+      // here (lower blocks get it from the LN1 partials of the block above).
+      const long long BW = 3 * E + rE + E;
+      float* bs = w.bslab + (size_t)l * VIT_SPLIT_CAP * BW;
+      pr[0].colsum = bs; pr[0].colsum_split_stride = BW;
+      pr[2].colsum = bs + 3 * E; pr[2].colsum_split_stride = BW;
+      if (l == top) { pr[3].colsum = bs + 3 * E + rE; pr[3].colsum_split_stride = BW; }
       VG_TRY(vg_gemm_launch(pr, 4, VG_TN, sd));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, sd));
+      vg_fold_push(folds, bs, pr[0].splits, (int)BW, G + lo + lay.bqkv, 3 * E, G + lo + lay.b1, rE, (l == top) ? G + lo + lay.b2 : nullptr, E,
+                   nullptr, 0);
     }
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;

@@ -288,6 +288,14 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
   const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
   const int g = lane >> 4, li = lane & 15;
 
+  // TN: bias-gradient column sums ride along (first n-tile, wn == 0 waves)
+  const bool do_cs = (MODE == VG_TN) && P.colsum != nullptr && tn == 0 && wn == 0;
+  f32x4 accb[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4];  // [nt][mt]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -385,6 +393,10 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn[nt], fm[mt], acc[nt][mt]);
+      if (MODE == VG_TN && do_cs) {  // rows of the result are all equal: sum_k A[k, m] lands on lane li = m, any register
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) accb[mt] = vg_mfma(ones, fm[mt], accb[mt]);
+      }
     }
     }
   }
@@ -398,6 +410,14 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
   // Problem fields are copied to registers first (a reference into kernarg memory is re-read after
   // every store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt
   // retires in order, so a load issued behind stores would wait for them.
+  if (MODE == VG_TN && do_cs && g == 0) {
+    float* cs = P.colsum + (size_t)split * P.colsum_split_stride;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + li;
+      if (m < P.M) cs[m] = accb[mt][0];
+    }
+  }
   STAMP(4);
   // ---- epilogue: registers only ---------------------------------------------------------------
   // A lane holds, per (n-tile, m-tile), 4 consecutive n of row li.  v_permlane16_swap between the even and the

@@ -38,6 +38,10 @@ struct VgGemmProb {
   // dropout on the output (NT only): drop_thresh = round(p*256) (0 = off); applied after bias/activation and BEFORE
   // the residual (drop_post = 0: x + drop(y)) or after every addend (drop_post = 1: drop(y + pos)); index = row*N + col
   unsigned drop_thresh, drop_key; float drop_scale; int drop_post; const unsigned* drop_step;
+  // TN only: column sums of A over k (= the bias gradient that goes with this weight gradient), one fp32 row [M] per
+  // K slice at colsum + s*colsum_split_stride (nullable).  Computed on the MFMA pipe (ones x A fragments) by the
+  // workgroups of the first n-tile: the wgrad kernel is L2->LDS bound, the extra MFMAs are free.
+  float* colsum; long long colsum_split_stride;
   // filled by the launcher
   int tiles_m, tiles_n, tile_start, k_per_split;
 };
