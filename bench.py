@@ -47,7 +47,7 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def gemm_roofline(torch, B):
-    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<1, 2, 0, 0>,
+    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<1, 4, 0, 0>,
     the input-gradient GEMM; timed at its heaviest shape, the QKV dgrad of the fused real+fake pass:
     dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.  Average launch duration is measured live with HIP
     events on the stream the kernel runs on; achieved = algorithmic FLOPs (2*M*N*K) / that duration.
@@ -83,7 +83,7 @@ def gemm_roofline(torch, B):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "kernel": "vg_gemm_kernel<1, 2, 0, 0> = NN input-gradient GEMM, 128x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
+            "traffic": traffic, "kernel": "vg_gemm_kernel<1, 4, 0, 0> = NN input-gradient GEMM, 256x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
             "algorithmic_flops_per_launch": 2.0 * M * N * K, "algorithmic_bytes_per_launch": 2 * (M * N + N * K + M * K),
             "avg_launch_us": round(ms * 1e3, 2)}
 
