@@ -97,6 +97,13 @@ int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S
 int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
                      void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
 
+/* The same fused attention with the v1 discriminator's L2-distance scores (src/v1/attention.py:43-52,66-67, lp = 2):
+ * out = softmax(cdist(q, k) * scale) @ v - the Euclidean distance itself, as the reference has it.  Same layouts. */
+int vg_attention_l2_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE,
+                        float scale, void* stream);
+int vg_attention_l2_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
+                        void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
+
 /* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1).
  * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */
 int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role,

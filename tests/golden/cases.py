@@ -19,3 +19,10 @@ GEN_CASES = {
     "g1": dict(batch=2, seed=21),
     "g1b3": dict(batch=3, seed=22),
 }
+
+# v1 MultiHeadSelfAttention with L2-distance scores (discriminator regulariser of src/v1/attention.py:54-67,73-103)
+V1ATT_CASES = {
+    "l2": dict(embed=384, heads=4, head_dim=96, seq=65, batch=2, seed=31, spectral=False),
+    "l2spec": dict(embed=384, heads=4, head_dim=96, seq=65, batch=2, seed=32, spectral=True),
+    "l2e128": dict(embed=128, heads=4, head_dim=32, seq=17, batch=3, seed=33, spectral=False),
+}

@@ -23,7 +23,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import GEN_CASES, VIT_CASES  # noqa: E402
+from cases import GEN_CASES, V1ATT_CASES, VIT_CASES  # noqa: E402
 from weights import make_input, make_state, summarize  # noqa: E402
 
 REF = os.environ.get("VITGAN_REFERENCE", "/root/reference")
@@ -164,8 +164,46 @@ def gen_case(v1g, name, c):
     print(f"gen_{name}: out {tuple(out.shape)} range [{float(out.min()):.3f}, {float(out.max()):.3f}]")
 
 
+def v1att_case(name, c):
+    """src/v1/attention.py MultiHeadSelfAttention with lp = 2 (cdist scores), optionally with the per-forward
+    spectral rescale.  init_spectrum is fixed at construction from the module's OWN random init (attention.py:37-39),
+    so it is recorded in the fixture and handed to the oracle as data."""
+    import src.v1.attention as v1a
+    from src.v1.config import TransformerParameters
+    torch.manual_seed(0)
+    tp = TransformerParameters(number_of_heads=c["heads"], input_features=c["embed"], lp=2, spectral_scaling=c["spectral"])
+    M = v1a.MultiHeadSelfAttention(tp, output_size=c["embed"], head_dimension=c["head_dim"])
+    shapes = {k: tuple(v.shape) for k, v in M.state_dict().items()}
+    st = make_state(shapes, c["seed"], "v1att")
+    M.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    x = torch.from_numpy(make_input((c["batch"], c["seq"], c["embed"]), c["seed"])).requires_grad_(True)
+    rec = {"torch_version": np.asarray(torch.__version__), "param_names": np.asarray(list(shapes.keys())),
+           "param_shapes": np.asarray([str(s) for s in shapes.values()])}
+    if c["spectral"]:
+        rec["init_spectrum"] = np.asarray([[float(v) for v in h.init_spectrum] for h in M.attention_heads], dtype=np.float64)
+    # head 0's score matrix before the softmax (the cdist) as a tap
+    h0 = M.attention_heads[0]
+    params_before = {k: p for k, p in M.named_parameters()}
+    out = M(x)
+    R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
+    (out * R).sum().backward()
+    rec["out"] = out.detach().numpy()
+    flat("dx", summarize(x.grad.numpy()), rec)
+    # with spectral scaling the forward REPLACES q/k/v weights by new Parameters (attention.py:60-64): gradients land
+    # on the replacements, which is what an optimizer built afterwards would see
+    for k, p in M.named_parameters():
+        flat(f"grad/{k}", summarize(p.grad.numpy()), rec)
+    with torch.no_grad():
+        q = h0.q(x); k_ = h0.k(x)
+        flat("tap/dist_h0", summarize(torch.cdist(q, k_, p=2).numpy()), rec)
+    np.savez_compressed(os.path.join(HERE, f"v1att_{name}.npz"), **rec)
+    print(f"v1att_{name}: out {tuple(out.shape)} |out| {float(out.abs().max()):.3f}")
+
+
 def main():
     v2m, v2u, v1g = import_reference()
+    for name, c in V1ATT_CASES.items():
+        v1att_case(name, c)
     for name, c in VIT_CASES.items():
         vit_case(v2m, v2u, name, c)
     vitgen_v2_case(v2m, v2u)

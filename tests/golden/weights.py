@@ -56,6 +56,11 @@ def make_state(shapes: Mapping[str, Tuple[int, ...]], seed: int, family: str) ->
                 out[name] = _draw(rng, shape, 1.0 / math.sqrt(shape[1]))
             else:
                 out[name] = _draw(rng, shape, 0.02)
+        elif family == "v1att":  # bias-free q/k/v [hd, E], output_linear [E_out, H*hd] (+ bias)
+            if leaf == "bias":
+                out[name] = _draw(rng, shape, 0.05)
+            else:
+                out[name] = _draw(rng, shape, 1.0 / math.sqrt(shape[1]))
         else:
             raise ValueError(family)
     return out

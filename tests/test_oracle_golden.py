@@ -126,3 +126,27 @@ def test_gen_oracle_matches_reference(name):
         _check_summary(npz, f"tap/block{i}", t.detach().numpy())
     for k, p in st.items():
         _check_summary(npz, f"grad/{k}", p.grad.numpy(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["l2", "l2spec", "l2e128"])
+def test_v1_l2_attention_oracle_matches_reference(name):
+    """v1 MultiHeadSelfAttention with cdist scores (and the spectral rescale) vs the reference."""
+    from cases import V1ATT_CASES
+    from oracle import v1att_oracle as ao
+    c = V1ATT_CASES[name]
+    npz = np.load(os.path.join(GOLD, f"v1att_{name}.npz"))
+    shapes = ao.v1att_param_shapes(c["embed"], c["heads"], c["head_dim"], c["embed"])
+    assert list(shapes.keys()) == [str(s) for s in npz["param_names"]]
+    assert [str(s) for s in shapes.values()] == [str(s) for s in npz["param_shapes"]]
+    st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in make_state(shapes, c["seed"], "v1att").items()}
+    x = torch.from_numpy(make_input((c["batch"], c["seq"], c["embed"]), c["seed"])).requires_grad_(True)
+    spec = npz["init_spectrum"] if c["spectral"] else None
+    taps = {}
+    out, used = ao.mhsa_l2_forward(st, x, c["heads"], c["head_dim"], spec, taps)
+    np.testing.assert_allclose(out.detach().numpy(), npz["out"], rtol=3e-4, atol=3e-5)
+    _check_summary(npz, "tap/dist_h0", taps["dist_h0"].detach().numpy())
+    R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
+    (out * R).sum().backward()
+    _check_summary(npz, "dx", x.grad.numpy(), rtol=1e-3)
+    for k, w in used.items():
+        _check_summary(npz, f"grad/{k}", w.grad.numpy(), rtol=1e-3)

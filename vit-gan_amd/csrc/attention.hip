@@ -116,14 +116,32 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
-template <int HE, int NT>
+// squared L2 norm of every row of an LDS head image -> out[rows] (rows >= S are zero rows).  One thread per row.
+template <int HE>
+__device__ __forceinline__ void row_sqnorms(const unsigned char* img, float* out, int rows, int tid, int nthreads) {
+  for (int r = tid; r < rows; r += nthreads) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HE / 8; ++c) {
+      const bf16x8 v = *(const bf16x8*)(img + lds_off<HE>(r, 8 * c));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = vg_bf2f(v[j]); a += f * f; }
+    }
+    out[r] = a;
+  }
+}
+// v1 attention score (src/v1/attention.py:66-67): the Euclidean distance |q - k| from q.k and the squared norms
+__device__ __forceinline__ float l2_dist(float qk, float qn, float kn) { return sqrtf(fmaxf(qn + kn - 2.f * qk, 0.f)); }
+
+template <int HE, int NT, bool L2>
 __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                               float* __restrict__ lse, int S, int H, float scale,
                                                               const void* __restrict__ zeros) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32, RK = 16 * NT;
-  __shared__ __attribute__((aligned(16))) unsigned char sm[(RK + RP) * HE * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char sm[(RK + RP) * HE * 2 + (L2 ? RK * 4 : 0)];
   unsigned char* kl = sm;                 // K, rows [0, 16 NT): row-form fragments
   unsigned char* vl = sm + RK * HE * 2;   // V, rows [0, 32 KP): transposed fragments
+  float* kn = (float*)(sm + (RK + RP) * HE * 2);  // L2 scores: |k|^2 per key
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6;  // wave qt owns query rows 16*qt .. 16*qt+15
   const int g = lane >> 4, li = lane & 15;
@@ -140,6 +158,16 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
   dma_head<HE, NT>(vl, vb, ld, S, RP, zeros, (qt + 2) % NT, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  float qn = 0.f;
+  if (L2) {
+    row_sqnorms<HE>(kl, kn, RK, tid, 64 * NT);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = vg_bf2f(qf[ks][j]); qn += f * f; }
+    qn = group_sum(qn);
+    __syncthreads();
+  }
 
   f32x4 sc[NT];  // [kt]: rows = keys 16kt+4g+r, col = query 16qt+li
 #pragma unroll
@@ -156,7 +184,8 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = 16 * kt + 4 * g + r;
-      const float sv = (key < S) ? sc[kt][r] * scale : -INFINITY;
+      const float raw = L2 ? l2_dist(sc[kt][r], qn, kn[key]) : sc[kt][r];
+      const float sv = (key < S) ? raw * scale : -INFINITY;
       sc[kt][r] = sv;
       m = fmaxf(m, sv);
     }
@@ -190,7 +219,7 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
 // Backward.  Phase A works in the S^T orientation (lane = query) and yields dQ; phase B in the
 // S orientation (lane = key) and yields dK, dV.  Recomputing the 65x65 tile in both orientations
 // costs 2 x 75 extra MFMAs per head and removes every register transpose.
-template <int HE, int NT>
+template <int HE, int NT, bool L2>
 __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, int S, int H, float scale,
@@ -199,13 +228,15 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
   constexpr int IMG = RP * HE * 2;
   // Everything a head needs is staged ONCE: K, V, Q, dO images (LDS-DMA) + lse and delta per query.  One load
   // phase, one compute phase, one store phase per workgroup; the co-resident workgroup overlaps them.
-  __shared__ __attribute__((aligned(16))) unsigned char sm[4 * IMG + 2 * RP * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4 * IMG + (L2 ? 4 : 2) * RP * 4];
   unsigned char* lk = sm;
   unsigned char* lv = sm + IMG;
   unsigned char* lq = sm + 2 * IMG;
   unsigned char* ldo = sm + 3 * IMG;
   float* dl = (float*)(sm + 4 * IMG);  // delta[q] = sum_d dO*O
   float* ll = dl + RP;                 // lse[q]
+  float* qn_l = ll + RP;               // L2 scores: |q|^2 per query, |k|^2 per key
+  float* kn_l = qn_l + RP;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
   const int g = lane >> 4, li = lane & 15;
@@ -247,6 +278,7 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
     const float delta = group_sum(dpart);
     if (g == 0) dl[16 * wv + li] = delta;
   }
+  if (L2) { row_sqnorms<HE>(lq, qn_l, RP, tid, 64 * NT); row_sqnorms<HE>(lk, kn_l, RP, tid, 64 * NT); }
   __syncthreads();
 
   // ---------------- phase A: S^T orientation (lane = query) -> dQ ----------------------
@@ -255,6 +287,8 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
     const int q = 16 * qt + li;
     const float delta = dl[q];
     const float lse_q = ll[q];
+    const float qn = L2 ? qn_l[q] : 0.f;
+    float wsum = 0.f;  // L2: sum_k W[q,k], W = dL/d dist / dist
     f32x4 ds[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
@@ -264,13 +298,19 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
         st = vg_mfma(lfrag_row<HE>(lk, 16 * kt, ks, lane), qf[ks], st);
         dpt = vg_mfma(lfrag_row<HE>(lv, 16 * kt, ks, lane), dof[ks], dpt);
       }
+      f32x4 kn4 = zero;
+      if (L2) kn4 = *(const f32x4*)(kn_l + 16 * kt + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kt + 4 * g + r;
-        const float p = (key < S && q < S) ? __expf(st[r] * scale - lse_q) : 0.f;
-        ds[kt][r] = p * (dpt[r] - delta) * scale;
+        const float raw = L2 ? l2_dist(st[r], qn, kn4[r]) : st[r];
+        const float p = (key < S && q < S) ? __expf(raw * scale - lse_q) : 0.f;
+        float dsv = p * (dpt[r] - delta) * scale;
+        if (L2) { dsv = raw > 0.f ? dsv / raw : 0.f; wsum += dsv; }  // d dist/dq = (q - k)/dist
+        ds[kt][r] = dsv;
       }
     }
+    if (L2) wsum = group_sum(wsum);
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero;
@@ -279,6 +319,14 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       const bf16x8 dsf = pack_pair(ds[2 * u], (2 * u + 1 < NT) ? ds[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = vg_mfma(lfrag_tr<HE>(lk, u, 16 * dt, lane), dsf, dq[dt]);
+    }
+    if (L2) {  // dQ = rowsum(W) q - W K
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x4 qv = *(const bf16x4*)(lq + lds_off<HE>(q, 16 * dt + 4 * g));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[dt][r] = wsum * vg_bf2f(qv[r]) - dq[dt][r];
+      }
     }
     store_tiles<DT>(dqb + (size_t)(q < S ? q : 0) * ld, dq, 1.0f, g, q < S);
   }
@@ -293,6 +341,8 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       vf[ks] = lfrag_row<HE>(lv, 16 * kt, ks, lane);
     }
     f32x4 pr[NT], ds[NT];
+    const float kn = L2 ? kn_l[key] : 0.f;
+    float wsum = 0.f;  // L2: sum_q W[q,key]
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       f32x4 s = zero, dp = zero;
@@ -303,15 +353,21 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       }
       const f32x4 lq4 = *(const f32x4*)(ll + 16 * qt + 4 * g);
       const f32x4 dl4 = *(const f32x4*)(dl + 16 * qt + 4 * g);
+      f32x4 qn4 = zero;
+      if (L2) qn4 = *(const f32x4*)(qn_l + 16 * qt + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = 16 * qt + 4 * g + r;
         const bool ok = (q < S) && (key < S);
-        const float p = ok ? __expf(s[r] * scale - lq4[r]) : 0.f;
+        const float raw = L2 ? l2_dist(s[r], qn4[r], kn) : s[r];
+        const float p = ok ? __expf(raw * scale - lq4[r]) : 0.f;
         pr[qt][r] = p;
-        ds[qt][r] = p * (dp[r] - dl4[r]) * scale;
+        float dsv = p * (dp[r] - dl4[r]) * scale;
+        if (L2) { dsv = raw > 0.f ? dsv / raw : 0.f; wsum += dsv; }  // d dist/dk = (k - q)/dist
+        ds[qt][r] = dsv;
       }
     }
+    if (L2) wsum = group_sum(wsum);
     f32x4 dv[DT], dk[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dv[dt] = zero; dk[dt] = zero; }
@@ -324,6 +380,14 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       for (int dt = 0; dt < DT; ++dt) {
         dv[dt] = vg_mfma(lfrag_tr<HE>(ldo, u, 16 * dt, lane), pf, dv[dt]);
         dk[dt] = vg_mfma(lfrag_tr<HE>(lq, u, 16 * dt, lane), dsf, dk[dt]);
+      }
+    }
+    if (L2) {  // dK = colsum(W) k - W^T Q
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x4 kv = *(const bf16x4*)(lk + lds_off<HE>(key, 16 * dt + 4 * g));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dk[dt][r] = wsum * vg_bf2f(kv[r]) - dk[dt][r];
       }
     }
     bf16* rowp = dqb + (size_t)(key < S ? key : 0) * ld;
@@ -339,37 +403,40 @@ static const void* attn_zeros() {
   return zp;
 }
 
-template <int HE, int NT>
+template <int HE, int NT, bool L2>
 static int launch_fwd(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
-  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT, L2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
   return (int)hipGetLastError();
 }
-template <int HE, int NT>
+template <int HE, int NT, bool L2>
 static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
                       int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
-  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, L2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
   return (int)hipGetLastError();
 }
 
-// Supported shapes: head dim 64 or 96; S <= 32 (2 tiles) or S <= 80 (5 tiles).
-int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, hipStream_t st) {
-  if (S < 1 || S > 80 || B < 1 || H < 1) return -2;
-  const bool small = (S <= 32);
-  if (HE == 96) return small ? launch_fwd<96, 2>(qkv, o, lse, B, H, S, scale, st) : launch_fwd<96, 5>(qkv, o, lse, B, H, S, scale, st);
-  if (HE == 64) return small ? launch_fwd<64, 2>(qkv, o, lse, B, H, S, scale, st) : launch_fwd<64, 5>(qkv, o, lse, B, H, S, scale, st);
-  if (HE == 32) return small ? launch_fwd<32, 2>(qkv, o, lse, B, H, S, scale, st) : launch_fwd<32, 5>(qkv, o, lse, B, H, S, scale, st);
-  return -3;
+// Supported shapes: head dim 32, 64 or 96; S <= 32 (2 tiles) or S <= 80 (5 tiles).
+// l2 = 0: dot-product scores (src/v2/modules.py:142-155, v1 lp = 1); l2 = 1: Euclidean-distance scores (v1 lp = 2).
+#define VG_ATTN_DISPATCH(FN, ...)                                                                       \
+  do {                                                                                                  \
+    if (S < 1 || S > 80 || B < 1 || H < 1) return -2;                                                   \
+    const bool small = (S <= 32);                                                                       \
+    if (HE == 96) return l2 ? (small ? FN<96, 2, true>(__VA_ARGS__) : FN<96, 5, true>(__VA_ARGS__))      \
+                            : (small ? FN<96, 2, false>(__VA_ARGS__) : FN<96, 5, false>(__VA_ARGS__));   \
+    if (HE == 64) return l2 ? (small ? FN<64, 2, true>(__VA_ARGS__) : FN<64, 5, true>(__VA_ARGS__))      \
+                            : (small ? FN<64, 2, false>(__VA_ARGS__) : FN<64, 5, false>(__VA_ARGS__));   \
+    if (HE == 32) return l2 ? (small ? FN<32, 2, true>(__VA_ARGS__) : FN<32, 5, true>(__VA_ARGS__))      \
+                            : (small ? FN<32, 2, false>(__VA_ARGS__) : FN<32, 5, false>(__VA_ARGS__));   \
+    return -3;                                                                                          \
+  } while (0)
+int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, int l2, hipStream_t st) {
+  VG_ATTN_DISPATCH(launch_fwd, qkv, o, lse, B, H, S, scale, st);
 }
 int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
-                       int S, int HE, float scale, hipStream_t st) {
-  if (S < 1 || S > 80 || B < 1 || H < 1) return -2;
-  const bool small = (S <= 32);
-  if (HE == 96) return small ? launch_bwd<96, 2>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st) : launch_bwd<96, 5>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
-  if (HE == 64) return small ? launch_bwd<64, 2>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st) : launch_bwd<64, 5>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
-  if (HE == 32) return small ? launch_bwd<32, 2>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st) : launch_bwd<32, 5>(qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
-  return -3;
+                       int S, int HE, float scale, int l2, hipStream_t st) {
+  VG_ATTN_DISPATCH(launch_bwd, qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
 }

@@ -81,12 +81,22 @@ extern "C" int vg_dropout_apply(const void* x, void* y, long long n, float p, un
 }
 extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;
-  return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, (hipStream_t)stream);
+  return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, 0, (hipStream_t)stream);
 }
 extern "C" int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* d_qkv, int B, int H,
                                 int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !d_out || !lse || !d_qkv) return -1;
-  return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale,
+  return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale, 0,
+                            (hipStream_t)stream);
+}
+extern "C" int vg_attention_l2_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !lse) return -1;
+  return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, 1, (hipStream_t)stream);
+}
+extern "C" int vg_attention_l2_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* d_qkv, int B, int H,
+                                   int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !d_out || !lse || !d_qkv) return -1;
+  return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale, 1,
                             (hipStream_t)stream);
 }
 extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role, float grad_scale,

@@ -292,7 +292,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
                             w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), 0, st));
     VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
     VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
                             w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
@@ -380,7 +380,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
                             drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), 0, st));
     VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     // LN1 backward writes dL/dX[l] (and its masked copy for the dropout it meets next) into the OTHER set, which the
     // weight-gradient side of block l+1 may still be reading: wait for it first
@@ -548,7 +548,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
     VG_TRY(vg_sln_fwd_launch(h, hb, w.wmod, P + lo + lay.sln1_w, P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1,
                              s1, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, R, E, 1e-5f, st));
     VG_TRY(lin_fwd(s1, E, Pb + lo + lay.wqkv, nullptr, qkv, R, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    VG_TRY(vg_attn_fwd_launch(qkv, cat, w.lse + (size_t)l * B * d.H * T, B, d.H, T, HE, scale, st));
+    VG_TRY(vg_attn_fwd_launch(qkv, cat, w.lse + (size_t)l * B * d.H * T, B, d.H, T, HE, scale, 0, st));
     {  // htmp = output_linear(cat) + h   (transformer.py:86); block 0 adds the broadcast embedding
       VgGemmProb p = mk(cat, E, Pb + lo + lay.wo, E, R, E, E);
       p.C = htmp; p.ldc = E; p.bias = P + lo + lay.bo;
@@ -640,7 +640,7 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
                  G + lo + lay.sln2_s, 2);
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, st));
+    VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, 0, st));
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     {
       const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);

@@ -190,31 +190,38 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class AttentionFn(torch.autograd.Function):
-    """softmax(scale q k^T) v over heads; qkv [B,S,3E] (Q|K|V thirds, head-major) -> [B,S,E].
-    src/v2/modules.py:142-159."""
+    """softmax(scale * score(q, k)) v over heads; qkv [B,S,3E] (Q|K|V thirds, head-major) -> [B,S,E].
+    lp = 1: score = q k^T (src/v2/modules.py:142-159, v1 attention.py:69-70); lp = 2: score = cdist(q, k), the v1
+    discriminator's L2 attention (attention.py:66-67)."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale):
+    def forward(ctx, qkv, heads, scale, lp=1):
         _need_cuda(qkv, "attention")
+        if lp not in (1, 2):
+            raise ValueError(f"Unsupported norm for attention: lp={lp} but should be 1 or 2")
         B, S, E3 = qkv.shape
         E = E3 // 3
         HE = E // heads
         qb = _bf(qkv).reshape(B * S, E3)
         out = torch.empty(B * S, E, dtype=BF, device=qkv.device)
         lse = torch.empty(B, heads, S, dtype=torch.float32, device=qkv.device)
-        _lib.check(_lib.lib().vg_attention_fwd(_p(qb), _p(out), _p(lse), B, heads, S, HE, scale, _st()), "vg_attention_fwd")
+        L = _lib.lib()
+        fn = L.vg_attention_fwd if lp == 1 else L.vg_attention_l2_fwd
+        _lib.check(fn(_p(qb), _p(out), _p(lse), B, heads, S, HE, scale, _st()), "vg_attention_fwd")
         ctx.save_for_backward(qb, out, lse)
-        ctx.dims = (B, heads, S, HE, scale, qkv.dtype)
+        ctx.dims = (B, heads, S, HE, scale, qkv.dtype, lp)
         return out.reshape(B, S, E).to(qkv.dtype)
 
     @staticmethod
     def backward(ctx, dout):
         qb, out, lse = ctx.saved_tensors
-        B, H, S, HE, scale, dt = ctx.dims
+        B, H, S, HE, scale, dt, lp = ctx.dims
         dob = _bf(dout).reshape(B * S, H * HE)
         dqkv = torch.empty_like(qb)
-        _lib.check(_lib.lib().vg_attention_bwd(_p(qb), _p(out), _p(dob), _p(lse), _p(dqkv), B, H, S, HE, scale, _st()), "vg_attention_bwd")
-        return dqkv.reshape(B, S, 3 * H * HE).to(dt), None, None
+        L = _lib.lib()
+        fn = L.vg_attention_bwd if lp == 1 else L.vg_attention_l2_bwd
+        _lib.check(fn(_p(qb), _p(out), _p(dob), _p(lse), _p(dqkv), B, H, S, HE, scale, _st()), "vg_attention_bwd")
+        return dqkv.reshape(B, S, 3 * H * HE).to(dt), None, None, None
 
 
 def linear(x, weight, bias=None, res=None):
@@ -229,7 +236,7 @@ def layer_norm(x, gamma, beta, eps: float = 1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
-def attention(qkv, heads: int, scale: Optional[float] = None):
+def attention(qkv, heads: int, scale: Optional[float] = None, lp: int = 1):
     if scale is None:
         scale = 1.0 / math.sqrt(qkv.shape[-1] // 3 // heads)
-    return AttentionFn.apply(qkv, heads, scale)
+    return AttentionFn.apply(qkv, heads, scale, lp)
