@@ -104,6 +104,14 @@ int vg_attention_l2_fwd(const void* qkv, void* out, float* lse, int B, int H, in
 int vg_attention_l2_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
                         void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
 
+/* v1 overlapping-window tokeniser (src/v1/patch_encoder.py:20-27,54-73): windows of P + 2*overlap pixels at stride
+ * (IH - P - 2*overlap)/P + 1, n x n of them; tokens bf16 [B, n*n, C*W*W] is the reference's FLAT view of the
+ * (b, c, ty, tx, wy, wx) unfold order (no permute).  img fp32 or bf16 [B,C,IH,IH]; _bwd is the adjoint (d_img bf16). */
+int vg_unfold_tokens_fwd(const void* img, int img_is_bf16, void* tokens, int B, int C, int IH, int P,
+                         int overlap, void* stream);
+int vg_unfold_tokens_bwd(const void* d_tokens, void* d_img, int B, int C, int IH, int P, int overlap,
+                         void* stream);
+
 /* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1).
  * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */
 int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role,

@@ -200,8 +200,25 @@ def v1att_case(name, c):
     print(f"v1att_{name}: out {tuple(out.shape)} |out| {float(out.abs().max()):.3f}")
 
 
+def v1tokens_case():
+    """src/v1/patch_encoder.py:54-73 ``_get_tokens`` (the module itself cannot be constructed: its __init__ reads an
+    attribute it never sets), called unbound on a stand-in carrying the three attributes it uses."""
+    import src.v1.patch_encoder as pe
+    rec = {"torch_version": np.asarray(torch.__version__)}
+    for tag, (B, C, IH, P, ov) in {"a": (2, 3, 32, 8, 2), "b": (1, 3, 16, 4, 1), "c": (2, 1, 28, 4, 0)}.items():
+        stride = (IH - P - 2 * ov) // P + 1  # patch_encoder.py:20-22
+        me = types.SimpleNamespace(patch_size=P, overlap=ov, stride=stride)
+        x = torch.from_numpy(make_input((B, C, IH, IH), 40 + B + IH, "uniform"))
+        tok = pe.PatchEncoder._get_tokens(me, x)
+        rec[f"{tag}/geometry"] = np.asarray([B, C, IH, P, ov], dtype=np.int64)
+        rec[f"{tag}/tokens"] = tok.numpy()
+    np.savez_compressed(os.path.join(HERE, "v1tokens.npz"), **rec)
+    print("v1tokens:", {k: rec[k].shape for k in rec if k.endswith("tokens")})
+
+
 def main():
     v2m, v2u, v1g = import_reference()
+    v1tokens_case()
     for name, c in V1ATT_CASES.items():
         v1att_case(name, c)
     for name, c in VIT_CASES.items():

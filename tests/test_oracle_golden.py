@@ -150,3 +150,13 @@ def test_v1_l2_attention_oracle_matches_reference(name):
     _check_summary(npz, "dx", x.grad.numpy(), rtol=1e-3)
     for k, w in used.items():
         _check_summary(npz, f"grad/{k}", w.grad.numpy(), rtol=1e-3)
+
+
+def test_v1_overlapping_tokeniser_oracle_matches_reference():
+    """PatchEncoder._get_tokens (flat view of the double unfold) - exact, it only moves data."""
+    from oracle import v1att_oracle as ao
+    npz = np.load(os.path.join(GOLD, "v1tokens.npz"))
+    for tag in ("a", "b", "c"):
+        B, C, IH, P, ov = (int(v) for v in npz[f"{tag}/geometry"])
+        x = torch.from_numpy(make_input((B, C, IH, IH), 40 + B + IH, "uniform"))
+        np.testing.assert_array_equal(ao.unfold_tokens(x, P, ov).numpy(), npz[f"{tag}/tokens"])

@@ -74,3 +74,28 @@ def test_v1_mhsa_module_vs_golden_and_oracle(name):
     got = dict(M.named_parameters())
     for k in ("attention_heads.0.q.weight", "attention_heads.1.k.weight", "attention_heads.3.v.weight", "output_linear.weight", "output_linear.bias"):
         u.assert_close(got[k].grad, used[k].grad, 2.0 ** -5, f"grad {k}", floor=1e-4)
+
+
+@pytest.mark.parametrize("B,C,IH,P,ov", [(2, 3, 32, 8, 2), (1, 3, 16, 4, 1), (2, 1, 28, 4, 0), (3, 3, 64, 8, 2)])
+def test_overlapping_tokeniser_vs_oracle(B, C, IH, P, ov):
+    """vg_unfold_tokens_fwd is a pure gather: bit-exact against the oracle on bf16 inputs; the adjoint sums at most
+    ceil(W/stride)^2 bf16 values per pixel in fp32 and rounds once: 2^-7 of max|ref|."""
+    import vit_gan_amd  # noqa: F401
+    from oracle import v1att_oracle as ao
+    from vit_gan_amd import ops
+    import gpu_util as u
+    g = torch.Generator().manual_seed(IH + P)
+    x = (torch.rand(B, C, IH, IH, generator=g) * 2 - 1).to(torch.bfloat16)
+    ref_in = x.float().requires_grad_(True)
+    ref = ao.unfold_tokens(ref_in, P, ov)
+    xd = x.cuda().requires_grad_(True)
+    tok = ops.unfold_tokens(xd, P, ov)
+    assert tok.shape == ref.shape and tok.dtype == torch.bfloat16
+    assert torch.equal(tok.float().cpu(), ref.detach())
+    R = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    (ref * R.float()).sum().backward()
+    (tok.float() * R.cuda().float()).sum().backward()
+    u.assert_close(xd.grad, ref_in.grad, 2.0 ** -7, "d images")
+    # fp32 images take the same path (rounded to bf16 on the way in)
+    tok32 = ops.unfold_tokens(x.float().cuda(), P, ov)
+    assert tok32.dtype == torch.float32 and torch.equal(tok32.cpu(), ref.detach())

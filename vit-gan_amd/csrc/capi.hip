@@ -99,6 +99,14 @@ extern "C" int vg_attention_l2_bwd(const void* qkv, const void* out, const void*
   return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale, 1,
                             (hipStream_t)stream);
 }
+extern "C" int vg_unfold_tokens_fwd(const void* img, int img_is_bf16, void* tokens, int B, int C, int IH, int P, int overlap, void* stream) {
+  if (!img || !tokens || B < 1 || C < 1) return -1;
+  return vg_unfold_tokens_launch(img, img_is_bf16, (bf16*)tokens, B, C, IH, P, overlap, (hipStream_t)stream);
+}
+extern "C" int vg_unfold_tokens_bwd(const void* d_tokens, void* d_img, int B, int C, int IH, int P, int overlap, void* stream) {
+  if (!d_tokens || !d_img || B < 1 || C < 1) return -1;
+  return vg_unfold_tokens_bwd_launch((const bf16*)d_tokens, (bf16*)d_img, B, C, IH, P, overlap, (hipStream_t)stream);
+}
 extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role, float grad_scale,
                            void* stream) {
   if (!logits || !dlogits || !loss_out || n < 1) return -1;

@@ -266,6 +266,68 @@ __global__ __launch_bounds__(256) void vg_sin_grad_kernel(const bf16* __restrict
 // --------------------------------------- launchers ---------------------------------------------
 static inline unsigned nblk(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
+// ---- v1 overlapping-window tokeniser (src/v1/patch_encoder.py:54-73) ---------------------------------------------
+// images.unfold(2, W, stride).unfold(3, W, stride) has shape [B, C, n, n, W, W]; the reference then takes a FLAT view
+// of that (b, c, ty, tx, wy, wx) memory order as [B, n*n, C*W*W] - no permute - and so does this kernel: element f of
+// image b's output is window pixel (c, ty, tx, wy, wx) with f = (((c*n + ty)*n + tx)*W + wy)*W + wx.
+template <typename T>
+__global__ __launch_bounds__(256) void vg_unfold_tokens_kernel(const T* __restrict__ img, bf16* __restrict__ out, int B, int C,
+                                                               int IH, int W, int stride, int n) {
+  const long long per = (long long)C * n * n * W * W, total = (long long)B * per;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / per);
+  long long f = i - (long long)b * per;
+  const int wx = (int)(f % W); f /= W;
+  const int wy = (int)(f % W); f /= W;
+  const int tx = (int)(f % n); f /= n;
+  const int ty = (int)(f % n);
+  const int c = (int)(f / n);
+  out[i] = vg_f2bf((float)img[(((size_t)b * C + c) * IH + ty * stride + wy) * IH + tx * stride + wx]);
+}
+// adjoint: every pixel gathers the gradient of each window that covers it (fixed order: deterministic, no atomics)
+__global__ __launch_bounds__(256) void vg_unfold_tokens_bwd_kernel(const bf16* __restrict__ dout, bf16* __restrict__ dimg, int B,
+                                                                   int C, int IH, int W, int stride, int n) {
+  const long long total = (long long)B * C * IH * IH;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % IH);
+  long long t = i / IH;
+  const int y = (int)(t % IH); t /= IH;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  const long long per = (long long)C * n * n * W * W;
+  const int ty0 = y >= W ? (y - W) / stride + 1 : 0, tx0 = x >= W ? (x - W) / stride + 1 : 0;
+  float a = 0.f;
+  for (int ty = ty0; ty < n && ty * stride <= y; ++ty)
+    for (int tx = tx0; tx < n && tx * stride <= x; ++tx) {
+      const int wy = y - ty * stride, wx = x - tx * stride;
+      a += vg_bf2f(dout[(size_t)b * per + ((((size_t)c * n + ty) * n + tx) * W + wy) * W + wx]);
+    }
+  dimg[i] = vg_f2bf(a);
+}
+static int unfold_geometry(int IH, int P, int overlap, int* W, int* stride, int* n) {
+  if (IH < 1 || P < 1 || overlap < 0) return -3;
+  *W = P + 2 * overlap;
+  if (*W > IH) return -3;
+  *stride = (IH - P - 2 * overlap) / P + 1;  // patch_encoder.py:20-22
+  *n = (IH - (*W - 1) - 1) / *stride + 1;    // :23-27 (== unfold's window count)
+  return 0;
+}
+int vg_unfold_tokens_launch(const void* img, int img_is_bf16, bf16* out, int B, int C, int IH, int P, int overlap, hipStream_t st) {
+  int W, stride, n;
+  if (unfold_geometry(IH, P, overlap, &W, &stride, &n)) return -3;
+  const long long total = (long long)B * C * n * n * W * W;
+  if (img_is_bf16) hipLaunchKernelGGL(vg_unfold_tokens_kernel<bf16>, dim3(nblk(total)), dim3(256), 0, st, (const bf16*)img, out, B, C, IH, W, stride, n);
+  else hipLaunchKernelGGL(vg_unfold_tokens_kernel<float>, dim3(nblk(total)), dim3(256), 0, st, (const float*)img, out, B, C, IH, W, stride, n);
+  return (int)hipGetLastError();
+}
+int vg_unfold_tokens_bwd_launch(const bf16* dout, bf16* dimg, int B, int C, int IH, int P, int overlap, hipStream_t st) {
+  int W, stride, n;
+  if (unfold_geometry(IH, P, overlap, &W, &stride, &n)) return -3;
+  hipLaunchKernelGGL(vg_unfold_tokens_bwd_kernel, dim3(nblk((long long)B * C * IH * IH)), dim3(256), 0, st, dout, dimg, B, C, IH, W, stride, n);
+  return (int)hipGetLastError();
+}
 int vg_patchify_launch(const void* img, int img_is_bf16, bf16* A, int B, int C, int IH, int P, hipStream_t st) {
   if (IH % P) return -3;
   const long long total = (long long)B * C * IH * (IH / P);

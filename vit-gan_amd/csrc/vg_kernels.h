@@ -31,6 +31,8 @@ int vg_colsum_bf16_launch(const bf16* X, long long ld, int R, int N, float* part
 
 int vg_patchify_launch(const void* img, int img_is_bf16, bf16* A, int B, int C, int IH, int P, hipStream_t st);
 int vg_unpatchify_launch(const bf16* dA, bf16* dimg, int B, int C, int IH, int P, hipStream_t st);
+int vg_unfold_tokens_launch(const void* img, int img_is_bf16, bf16* out, int B, int C, int IH, int P, int overlap, hipStream_t st);
+int vg_unfold_tokens_bwd_launch(const bf16* dout, bf16* dimg, int B, int C, int IH, int P, int overlap, hipStream_t st);
 int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
                        hipStream_t st);
 int vg_dropout_apply_launch(const bf16* x, bf16* y, long long n, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,

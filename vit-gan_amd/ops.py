@@ -224,6 +224,38 @@ class AttentionFn(torch.autograd.Function):
         return dqkv.reshape(B, S, 3 * H * HE).to(dt), None, None, None
 
 
+class UnfoldTokensFn(torch.autograd.Function):
+    """v1 overlapping-window tokeniser (src/v1/patch_encoder.py:54-73): [B,C,IH,IH] -> [B, n*n, C*W*W], the reference's
+    flat view of the double unfold; backward gathers every covering window per pixel."""
+
+    @staticmethod
+    def forward(ctx, images, patch, overlap):
+        _need_cuda(images, "unfold_tokens")
+        B, C, IH, IW = images.shape
+        assert IH == IW, "The provided images are not square shaped"
+        W = patch + 2 * overlap
+        stride = (IH - patch - 2 * overlap) // patch + 1
+        n = (IH - (W - 1) - 1) // stride + 1
+        is_bf = images.dtype == BF
+        src = images.contiguous() if is_bf else images.float().contiguous()
+        out = torch.empty(B, n * n, C * W * W, dtype=BF, device=images.device)
+        _lib.check(_lib.lib().vg_unfold_tokens_fwd(_p(src), int(is_bf), _p(out), B, C, IH, patch, overlap, _st()), "vg_unfold_tokens_fwd")
+        ctx.geo = (B, C, IH, patch, overlap, images.dtype)
+        return out.to(images.dtype)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        B, C, IH, patch, overlap, dt = ctx.geo
+        d = _bf(dtok).contiguous()
+        dimg = torch.empty(B, C, IH, IH, dtype=BF, device=dtok.device)
+        _lib.check(_lib.lib().vg_unfold_tokens_bwd(_p(d), _p(dimg), B, C, IH, patch, overlap, _st()), "vg_unfold_tokens_bwd")
+        return dimg.to(dt), None, None
+
+
+def unfold_tokens(images, patch: int, overlap: int):
+    return UnfoldTokensFn.apply(images, patch, overlap)
+
+
 def linear(x, weight, bias=None, res=None):
     return LinearFn.apply(x, weight, bias, res)
 
