@@ -22,9 +22,21 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The reference's algorithm (oracle = fp32 CPU restatement pinned to the reference's outputs) timed
-    on this box's host cores: config C1 (B=64, fp32), same step structure."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The reference's algorithm (oracle = fp32 CPU restatement pinned to the reference's outputs) timed on this box's
+    host cores: config C1 (B=64, fp32), same step structure; 2 warm-up steps, then 5 timed steps unless the
+    time budget runs out first (never fewer than 2)."""
     import torch
     from oracle import gen_oracle as go, step_oracle as so, vit_oracle as vo
 
@@ -34,16 +46,18 @@ def cpu_baseline(seconds_budget=25.0):
     g = torch.Generator().manual_seed(1234)
     real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
     z = torch.randn(B, gd.latent, generator=g)
-    oracle.step(real, z)  # warm-up
+    for _ in range(2):
+        oracle.step(real, z)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
         oracle.step(real, z)
         n += 1
         el = time.perf_counter() - t0
-        if n >= 2 and (el > seconds_budget or n >= 8):
+        if n >= 5 or (n >= 2 and el > seconds_budget):
             break
     return {"value": round(n * B / el, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full G+D steps at config C1 (B=64, fp32, torch {torch.__version__} CPU, os.cpu_count={os.cpu_count()})"}
+            "sample": f"{n} full G+D steps after 2 warm-ups at config C1 (B=64, fp32, torch {torch.__version__} CPU, "
+                      f"{_cpu_model()}, os.cpu_count={os.cpu_count()})"}
 
 
 def gemm_roofline(torch, B):
