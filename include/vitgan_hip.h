@@ -112,7 +112,8 @@ int vg_unfold_tokens_fwd(const void* img, int img_is_bf16, void* tokens, int B, 
 int vg_unfold_tokens_bwd(const void* d_tokens, void* d_img, int B, int C, int IH, int P, int overlap,
                          void* stream);
 
-/* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1).
+/* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1;
+ * kind 2 = the Wasserstein critic losses of src/v2/training.py:72,97).
  * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */
 int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role,
                 float grad_scale, void* stream);
@@ -124,6 +125,10 @@ int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int
 int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const int* step_dev, float gscale, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (the reference's Wasserstein step, src/v2/training.py:78,104) on a flat fp32 gradient
+ * buffer: g *= min(1, max_norm / (gscale*|g|_2 + 1e-6)) in place; scratch: 1 + 1024 floats of device memory,
+ * scratch[0] receives gscale*|g|_2.  Deterministic (no atomics).  n % 4 == 0. */
+int vg_grad_clip(float* g, long long n, float gscale, float max_norm, float* scratch, void* stream);
 int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ def d_loss_real(logits: Tensor, kind: str) -> Tensor:
         return F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
     if kind == "hinge":
         return F.relu(1.0 - logits).mean()
+    if kind == "wasserstein":  # src/v2/training.py:97: -(mean(real_output) - mean(fake_output)), the real half
+        return -logits.mean()
     raise ValueError(kind)
 
 
@@ -37,13 +39,15 @@ def d_loss_fake(logits: Tensor, kind: str) -> Tensor:
         return F.binary_cross_entropy_with_logits(logits, torch.zeros_like(logits))
     if kind == "hinge":
         return F.relu(1.0 + logits).mean()
+    if kind == "wasserstein":
+        return logits.mean()
     raise ValueError(kind)
 
 
 def g_loss(logits: Tensor, kind: str) -> Tensor:
     if kind == "ns":
         return F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
-    if kind == "hinge":
+    if kind in ("hinge", "wasserstein"):  # training.py:72: -torch.mean(output)
         return -logits.mean()
     raise ValueError(kind)
 
@@ -53,8 +57,9 @@ class GanStepOracle:
 
     def __init__(self, d_state: Mapping[str, Tensor], g_state: Mapping[str, Tensor],
                  ddims: VitDims, gdims: GenDims, lr_d: float = 5e-4, lr_g: float = 5e-4,
-                 weight_decay: float = 1e-3, loss: str = "ns"):
+                 weight_decay: float = 1e-3, loss: str = "ns", clip_d: float = None, clip_g: float = None):
         self.ddims, self.gdims, self.loss = ddims, gdims, loss
+        self.clip_d, self.clip_g = clip_d, clip_g  # utils.clip_grad_norm_ max norms (training.py:78,104), None = off
         self.d = {k: v.detach().clone().float().requires_grad_(True) for k, v in d_state.items()}
         self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
         self.opt_d = torch.optim.AdamW(list(self.d.values()), lr=lr_d, weight_decay=weight_decay)
@@ -74,10 +79,14 @@ class GanStepOracle:
         fake = self.G(z)
         loss_fake = d_loss_fake(self.D(fake.detach()), self.loss)
         loss_fake.backward()
+        if self.clip_d is not None:
+            torch.nn.utils.clip_grad_norm_(list(self.d.values()), max_norm=self.clip_d)
         self.opt_d.step()
         for p in self.g.values():
             p.grad = None
         loss_g = g_loss(self.D(fake), self.loss)
         loss_g.backward()
+        if self.clip_g is not None:
+            torch.nn.utils.clip_grad_norm_(list(self.g.values()), max_norm=self.clip_g)
         self.opt_g.step()
         return {"d_real": float(loss_real), "d_fake": float(loss_fake), "g": float(loss_g)}

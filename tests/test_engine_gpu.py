@@ -235,3 +235,32 @@ def test_engine_step_with_patch_grid_generator_at_c4_shape():
     ref = oracle.step(real, eng.z.detach().cpu().clone())
     got = losses.cpu().tolist()
     assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)
+
+
+def test_wasserstein_losses_and_gradient_clipping():
+    """The critic losses and clip_grad_norm_ limits of the reference's unreached Wasserstein step (training.py:72,78,
+    97,104) through GanEngine vs the step oracle; the clip limits are set low enough to be active."""
+    from vit_gan_amd.engine import GanEngine
+    import vit_gan_amd  # noqa: F401
+    from oracle import step_oracle as so
+
+    B = 8
+    D, G, oracle = _build(B, "wasserstein")
+    oracle.clip_d, oracle.clip_g = 0.05, 0.02
+    eng = GanEngine(D, G, batch=B, loss="wasserstein", clip_d=0.05, clip_g=0.02)
+    g = torch.Generator().manual_seed(0)
+    real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    w_before = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    losses = eng.step(real.cuda())
+    torch.cuda.synchronize()
+    ref = oracle.step(real, eng.z.detach().cpu().clone())
+    got = losses.cpu().tolist()
+    assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)
+    # the recorded norms are the pre-clip global norms and exceed the limits (clipping was active)
+    nd, ng = float(eng.clip_scratch[0, 0]), float(eng.clip_scratch[1, 0])
+    assert nd > 0.05 and ng > 0.02, (nd, ng)
+    k = "vit.encoder.1.fc2.weight"
+    upd = (D.state_dict()[k].detach().cpu() - w_before[k])
+    ref_upd = oracle.d[k].detach() - w_before[k]
+    assert float((upd - ref_upd).abs().max()) < 1.1e-3  # first AdamW step: +-lr per weight, sign flips on noise-level entries only
+    assert float(((upd - ref_upd).abs() < 1e-4).float().mean()) > 0.9

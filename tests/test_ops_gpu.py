@@ -5,6 +5,7 @@ remaining difference is accumulation order (fp32) plus ONE bf16 rounding of the 
 tolerance 2^-7 * max|ref| for bf16 outputs, 2e-5 * max|ref| for fp32 outputs (pre-activations,
 weight gradients, LSE, statistics).
 """
+import ctypes as C
 import math
 
 import pytest
@@ -247,3 +248,30 @@ def test_adamw_matches_torch():
         u.sync()
         u.assert_close(P, p.detach(), 1e-6, f"adamw step {step}")
         u.assert_close(SH, p.detach(), 2.0 ** -8, "bf16 shadow")
+
+
+def test_grad_clip_matches_torch():
+    import gpu_util as u
+    g = torch.Generator().manual_seed(3)
+    for n, max_norm, gscale in ((4096, 0.5, 1.0), (1 << 20, 5.0, 0.25), (1000 * 4, 100.0, 1.0)):
+        x = torch.randn(n, generator=g) * 0.01
+        p = torch.nn.Parameter(torch.zeros(n))
+        p.grad = (x * gscale).clone()
+        total = float(torch.nn.utils.clip_grad_norm_([p], max_norm))
+        xd = u.dev(x)
+        scratch = torch.zeros(1 + 1024, device="cuda")
+        u.call("vg_grad_clip", u.ptr(xd), C.c_longlong(n), C.c_float(gscale), C.c_float(max_norm), u.ptr(scratch), u.stream())
+        u.sync()
+        assert abs(float(scratch[0]) - total) <= 5e-5 * max(total, 1.0)  # fp32 sums of up to 1M squares in a different order
+        u.assert_close(xd * gscale, p.grad, 1e-4, "clipped gradient")
+
+
+def test_wasserstein_loss_kind():
+    import gpu_util as u
+    x = torch.randn(37, generator=torch.Generator().manual_seed(1))
+    for role, want, dw in ((0, -x.mean(), -1.0), (1, x.mean(), 1.0), (2, -x.mean(), -1.0)):
+        xd, dl, lo = u.dev(x), torch.empty(37, device="cuda"), torch.empty(1, device="cuda")
+        u.call("vg_gan_loss", u.ptr(xd), u.ptr(dl), u.ptr(lo), 37, 2, role, C.c_float(1.0), u.stream())
+        u.sync()
+        assert abs(float(lo) - float(want)) < 1e-6
+        assert torch.allclose(dl.cpu(), torch.full((37,), dw / 37))

@@ -119,6 +119,10 @@ extern "C" int vg_adamw_step(float* p, const float* g, float* m, float* v, void*
   return vg_adamw_launch(p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, step_dev, gscale,
                          (hipStream_t)stream);
 }
+extern "C" int vg_grad_clip(float* g, long long n, float gscale, float max_norm, float* scratch, void* stream) {
+  if (!g || !scratch || n < 1 || !(max_norm > 0.f)) return -1;
+  return vg_grad_clip_launch(g, n, gscale, max_norm, scratch, (hipStream_t)stream);
+}
 extern "C" int vg_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
   if (!src || !dst_bf16 || n < 1) return -1;
   return vg_cast_f32_bf16_launch(src, (bf16*)dst_bf16, n, (hipStream_t)stream);

@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restric
     const float hm = 1.f + sgn * x;
     const float l_h = (role == 2) ? -x : fmaxf(hm, 0.f);
     const float d_h = (role == 2) ? -1.f : ((hm > 0.f) ? sgn : 0.f);
-    const float l = (kind == 0) ? l_ns : l_h;
-    const float d = (kind == 0) ? d_ns : d_h;
+    const float l_w = (role == 1) ? x : -x;        // Wasserstein critic (src/v2/training.py:72,97): -(E[D(real)] - E[D(fake)]), G: -E[D(fake)]
+    const float d_w = (role == 1) ? 1.f : -1.f;
+    const float l = (kind == 0) ? l_ns : ((kind == 1) ? l_h : l_w);
+    const float d = (kind == 0) ? d_ns : ((kind == 1) ? d_h : d_w);
     acc += l;
     dlog[i] = d * inv * grad_scale;
   }
@@ -202,6 +204,49 @@ __global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+}
+
+// ---- torch.nn.utils.clip_grad_norm_ over a flat gradient buffer (src/v2/training.py:78,104) -------------------------
+// Two deterministic stages: per-workgroup sums of squares, then every workgroup folds the partials in the same fixed
+// order, derives coef = min(1, max_norm / (gscale*|g| + 1e-6)) and scales its slice in place.
+#define VG_CLIP_PARTS 1024
+__global__ __launch_bounds__(256) void vg_sumsq_part_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += (long long)gridDim.x * 1024) {
+    const f32x4 v = *(const f32x4*)(g + i4);
+    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  a = vg_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void vg_clip_scale_kernel(float* __restrict__ g, long long n, const float* __restrict__ part, int nparts,
+                                                            float gscale, float max_norm, float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+  a = vg_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * gscale;
+  const float coef = fminf(1.f, max_norm / (norm + 1e-6f));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  if (coef >= 1.f) return;
+  for (long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += (long long)gridDim.x * 1024) {
+    f32x4 v = *(f32x4*)(g + i4);
+    v *= coef;
+    *(f32x4*)(g + i4) = v;
+  }
+}
+int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, float* scratch, hipStream_t st) {
+  if (n & 3) return -3;
+  long long blocks = (n / 4 + 255) / 256;
+  const int nb = (int)(blocks < VG_CLIP_PARTS ? blocks : VG_CLIP_PARTS);
+  hipLaunchKernelGGL(vg_sumsq_part_kernel, dim3(nb), dim3(256), 0, st, g, n, scratch + 1);
+  hipLaunchKernelGGL(vg_clip_scale_kernel, dim3(nb), dim3(256), 0, st, g, n, scratch + 1, nb, gscale, max_norm, scratch);
+  return (int)hipGetLastError();
 }
 
 // ---- fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics) ----------------------
@@ -380,7 +425,7 @@ int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* 
 }
 int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
                        hipStream_t st) {
-  if (kind < 0 || kind > 1 || role < 0 || role > 2) return -2;
+  if (kind < 0 || kind > 2 || role < 0 || role > 2) return -2;
   hipLaunchKernelGGL(vg_gan_loss_kernel, dim3(1), dim3(256), 0, st, logit, dlog, loss_out, n, kind, role, grad_scale);
   return (int)hipGetLastError();
 }

@@ -26,7 +26,7 @@ from .dist import GradSync
 from .generator import SirenGenerator
 from .modules import ViTDiscriminator, VisionTransformer
 
-LOSS_KINDS = {"ns": 0, "hinge": 1}
+LOSS_KINDS = {"ns": 0, "hinge": 1, "wasserstein": 2}  # "wasserstein": the critic losses of src/v2/training.py:72,97
 
 
 def _p(t):
@@ -38,8 +38,10 @@ class GanEngine:
                  lr_d: float = 5e-4, lr_g: float = 5e-4, weight_decay: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
-                 concurrent_wgrad: bool = True,
+                 concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  process_group: Optional["dist.ProcessGroup"] = None):
+        """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
+        Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop)."""
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
             raise TypeError("GanEngine needs a ViTDiscriminator/VisionTransformer and a SirenGenerator")
@@ -56,6 +58,8 @@ class GanEngine:
         self.seed = int(seed)
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
+        self.clip_d, self.clip_g = clip_d, clip_g
+        self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
         self.sync = GradSync(process_group, self.dev, overlap=True)
         self.world = self.sync.world
@@ -114,8 +118,11 @@ class GanEngine:
         _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, 1 + half, nL + 2, st), "vg_vit_backward_stages")
         self.sync.reduce_range(fd.grad, 0, cut)
 
-    def _adamw(self, fp, m, v, lr, st):
+    def _adamw(self, fp, m, v, lr, st, clip=None, slot=0):
         h = self.hyp
+        if clip is not None:  # on the exchanged (global) gradient, like clip_grad_norm_ before optimizer.step()
+            _lib.check(_lib.lib().vg_grad_clip(_p(fp.grad), fp.total, 1.0 / self.world, float(clip), _p(self.clip_scratch[slot]), st),
+                       "vg_grad_clip")
         _lib.check(_lib.lib().vg_adamw_step(_p(fp.flat), _p(fp.grad), _p(m), _p(v), _p(fp.shadow), fp.total, lr, h["b1"], h["b2"],
                                             h["eps"], h["wd"], 0, _p(self.step_t), 1.0 / self.world, st), "vg_adamw_step")
 
@@ -156,7 +163,7 @@ class GanEngine:
                 else:  # second pass finishes D.grad: exchange it as it completes
                     self._d_backward(net, B, dl, 1, None, st)
         self.sync.wait()
-        self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st)
+        self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st, self.clip_d, 0)
         fg.grad.zero_()            # gan.generator.zero_grad(), training.py:199
         _lib.check(L.vg_vit_forward(C.byref(nd_c), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
         self._loss(0, B, 2, 2, st)
@@ -164,7 +171,7 @@ class GanEngine:
         _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
         self.sync.reduce_range(fg.grad, 0, fg.total)
         self.sync.wait()
-        self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st)
+        self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st, self.clip_g, 1)
 
     def step(self, real: torch.Tensor) -> torch.Tensor:
         """Run one G/D step on ``real`` [B,C,IH,IW] (cuda).  Returns the device tensor
