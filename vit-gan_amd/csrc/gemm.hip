@@ -1,17 +1,19 @@
 // bf16 MFMA GEMM family for the ViTGAN hot path (gfx950).
 //
-// One kernel template, three operand forms (vg_gemm.h).  Tile 128(m) x 128(n) x 32(k),
-// 256 threads = 4 waves as 2(m) x 2(n), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
-// LDS: a 4-stage ring of (8 KiB + 8 KiB) filled by LDS-DMA (global_load_lds_dwordx4); three
-// k-steps stay in flight across a raw s_barrier behind a COUNTED s_waitcnt vmcnt, because with
-// K = 384..1152 the kernel is L2-latency bound, not MFMA bound (2 workgroups/CU x 48 KiB in flight).
+// One kernel template, three operand forms (vg_gemm.h).  Tile 64*WM (m) x 128 (n) x 32 (k): WM = 2 -> 128 x 128,
+// 4 waves as 2(m) x 2(n); WM = 4 -> 256 x 128, 8 waves as 4(m) x 2(n); each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
+// LDS: a ring of NSTAGE stages filled by LDS-DMA (global_load_lds_dwordx4); NSTAGE-1 k-steps stay in flight across a
+// raw s_barrier behind a COUNTED s_waitcnt vmcnt.  Fragment reads are inline asm so that the compiler's conservative
+// `s_waitcnt vmcnt(0)` between an LDS-DMA and the next ds_read (it cannot tell the stages apart) does not drain the
+// ring at every step.  What bounds the family is the L2 -> LDS staging rate (~10 TB/s chip-wide):
+// FLOP/s follow flop per staged byte, i.e. the tile size.
 //
 // The MFMA is issued "swapped": its A operand carries the GEMM's n index and its B operand the
-// m index, so a lane's 4 accumulator registers are 4 CONSECUTIVE n of one output row m and the
-// epilogue stores 8 B (bf16) / 16 B (fp32) per lane straight from registers.
+// m index, so a lane's 4 accumulator registers are 4 CONSECUTIVE n of one output row m; the epilogue pairs
+// n-tiles with v_permlane16_swap and stores 16 B (bf16) / 32 B (fp32) per lane straight from registers.
 //
 // Operand images in LDS:
-//   row form  [128 rows][32 k]  (64-B rows): 16-B chunk c of row r lives at chunk c ^ F[(r>>2)&3],
+//   row form  [rows][32 k]  (64-B rows): 16-B chunk c of row r lives at chunk c ^ F[(r>>2)&3],
 //             F = {0,2,3,1}: the four 16-lane groups of a ds_read_b128 then each cover all 16
 //             slots of a 256-B bank row (conflict-free).
 //   tr  form  [32 k][128 cols]  (256-B rows): 16-B chunk c of row k lives at c ^ (2*sigma(k)),
@@ -22,14 +24,7 @@
 
 #define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
-#define BK 32           // k per MFMA sub-step
-#ifndef VG_ISSUE_LATE
-#define VG_ISSUE_LATE 0   // 1: issue the next stage's DMA after this step's fragment reads (only useful with VG_ASM_READS 0)
-#endif
-#ifndef VG_BKS
-#define VG_BKS 1        // MFMA sub-steps per LDS stage: a stage holds BKS = 32 * VG_BKS of k
-#endif
-#define BKS (BK * VG_BKS)
+#define BK 32           // k per LDS stage = one MFMA k-step
 #ifndef VG_ABLATE
 #define VG_ABLATE 0
 #endif
@@ -49,8 +44,8 @@
 #ifndef OCC_WM2
 #define OCC_WM2 4
 #endif
-#define A_TILE_BYTES (BM * BKS * 2)
-#define B_TILE_BYTES (BN * BKS * 2)
+#define A_TILE_BYTES (BM * BK * 2)
+#define B_TILE_BYTES (BN * BK * 2)
 #define STAGE_BYTES (A_TILE_BYTES + B_TILE_BYTES)
 
 __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
@@ -62,12 +57,8 @@ __device__ __forceinline__ int tr_sigma(int kk) { return (kk & 3) | (((kk >> 3) 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// row-form chunk swizzle.  64-B rows (VG_BKS 1): {0,2,3,1}[(r>>2)&3]; 128-B rows (VG_BKS 2): (r>>1)&7 - the 16 lanes
-// of a ds_read_b128 group then cover (row parity, chunk) = all 16 slots of a 256-B bank row.
-__device__ __forceinline__ int row_f(int r) {
-  if (VG_BKS == 1) return (0x78 >> (2 * ((r >> 2) & 3))) & 3;
-  return (r >> 1) & 7;
-}
+// row-form chunk swizzle: {0,2,3,1}[(r>>2)&3]
+__device__ __forceinline__ int row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
 
 // PIECES 1-KiB pieces per tile (8 per 128 rows/cols), dealt round-robin to the NW waves.
 // Addressing is split into a wave-UNIFORM base (tile origin at the current k, kept in SGPRs and advanced by one
@@ -87,26 +78,26 @@ struct Stager {
   // k offset (elements) of this lane's chunk inside a stage, piece j
   static __device__ __forceinline__ int lane_k(int j, int lane) {
     if (!TR) {
-      constexpr int LPR = 4 * VG_BKS;
+      constexpr int LPR = 4;
       const int rl = (64 / LPR) * j + lane / LPR;
       return ((lane & (LPR - 1)) ^ row_f(rl)) << 3;
     }
-    return 4 * (j % (8 * VG_BKS)) + (lane >> 4);
+    return 4 * (j % 8) + (lane >> 4);
   }
   __device__ __forceinline__ void setup(const bf16* __restrict__ X, int ld, int idx0, int idx_end, int k_begin, int wid, int lane) {
     base = (const char*)(X + (size_t)k_begin * (TR ? ld : 1));
-    step_bytes = (long long)BKS * (TR ? ld : 1) * 2;
+    step_bytes = (long long)BK * (TR ? ld : 1) * 2;
     k_cur = k_begin;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int j = wid + NW * i;
-      if (!TR) {  // piece = 16 rows x 64 B (VG_BKS 1) or 8 rows x 128 B = whole cache lines (VG_BKS 2)
-        constexpr int LPR = 4 * VG_BKS;  // lanes (16-B chunks) per row
+      if (!TR) {  // piece = 16 rows x 64 B
+        constexpr int LPR = 4;  // lanes (16-B chunks) per row
         const int rl = (64 / LPR) * j + lane / LPR;
         const int row = min(idx0 + rl, idx_end - 1);
         voff[i] = ((unsigned)row * (unsigned)ld + (unsigned)lane_k(j, lane)) * 2u;
-      } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 * VG_BKS pieces per sub-tile)
-        const int sub = j / (8 * VG_BKS);
+      } else {    // piece = 4 k-rows x 256 B of one 128-column sub-tile (8 pieces per sub-tile)
+        const int sub = j / 8;
         const int kk = lane_k(j, lane);
         const int c = (lane & 15) ^ (2 * tr_sigma(kk));
         const int col = min(idx0 + 128 * sub + (c << 3), idx_end - 8);
@@ -114,13 +105,13 @@ struct Stager {
       }
     }
   }
-  // full stage (k_cur + BKS <= k_end)
+  // full stage (k_cur + BK <= k_end)
   __device__ __forceinline__ void issue(unsigned char* tile, int wid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[i]), (lptr_t)(tile + 1024 * (wid + NW * i)), 16, 0, 0);
     base += step_bytes;
-    k_cur += BKS;
+    k_cur += BK;
   }
   // last, partial stage: chunks at k >= k_end come from the zero page
   __device__ __forceinline__ void issue_tail(unsigned char* tile, int k_end, const void* zeros, int wid, int lane) {
@@ -131,42 +122,16 @@ struct Stager {
       __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(tile + 1024 * j), 16, 0, 0);
     }
     base += step_bytes;
-    k_cur += BKS;
+    k_cur += BK;
   }
 };
 
-// ---- LDS -> MFMA fragment: 16 rows/cols starting at i0, k sub-step ks (32 wide) -------------
-template <bool TR>
-__device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int i0, int lane, int ks) {
-  const int g = lane >> 4, li = lane & 15;
-  if (!TR) {
-    const int row = i0 + li;
-    return *(const bf16x8*)(tile + row * (64 * VG_BKS) + (((4 * ks + g) ^ row_f(row)) << 4));
-  } else {
-    const int q = li >> 2, p = li & 3;
-    const int c8 = ((i0 & 127) >> 2) + p;
-    const int sw = 2 * (q | ((g & 1) << 2));
-    const int kk0 = 8 * g + q;
-    const unsigned char* a0 = tile + (i0 >> 7) * (8192 * VG_BKS) + (32 * ks + kk0) * 256 + ((((c8 >> 1) ^ sw)) << 4) + ((c8 & 1) << 3);
-    typedef bf16x4 __attribute__((address_space(3))) * lds4;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + 4 * 256));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  }
-}
-
-// ---- the same fragments by inline asm (VG_BKS == 1) -----------------------------------------------------
+// ---- LDS -> MFMA fragments, by inline asm ------------------------------------------------------------------
 // The compiler cannot tell an LDS-DMA's destination stage from the stage being read and puts `s_waitcnt vmcnt(0)`
 // in front of every ds_read that follows a global_load_lds - which drains the whole prefetch ring at every k-step
 // (a deeper ring then buys nothing).  Reads issued from inline asm carry no such dependence; the counted
 // `s_waitcnt vmcnt(N)` + `s_barrier` at the top of the step is the only synchronisation, as intended.
 // One asm block per step: all ds_reads of both operands, then s_waitcnt lgkmcnt(0).
-#ifndef VG_ASM_READS
-#define VG_ASM_READS (VG_BKS == 1)
-#endif
 // loop-invariant LDS byte offsets (inside a stage) of a wave's fragments
 template <bool TR>
 struct FragAddr {
@@ -314,16 +279,16 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
 #else
 #define STAMP(i)
 #endif
-  const int nsteps = (k_end - k_begin + BKS - 1) / BKS;
-  Stager<A_TR, 4 * WM * VG_BKS, NW> sa;
-  Stager<B_TR, 8 * VG_BKS, NW> sb;
+  const int nsteps = (k_end - k_begin + BK - 1) / BK;
+  Stager<A_TR, 4 * WM, NW> sa;
+  Stager<B_TR, 8, NW> sb;
   sa.setup(Ag, lda, m0, P.M, k_begin, wid, lane);
   sb.setup(Bg, ldb, n0, P.N, k_begin, wid, lane);
   // stages are issued strictly in order (prologue, then one per k-step), so the stagers keep a running k
 #define ISSUE(step)                                                                                      \
   do {                                                                                                   \
     unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
-    if (sa.k_cur + BKS <= k_end) {                                                                       \
+    if (sa.k_cur + BK <= k_end) {                                                                       \
       sa.issue(_b, wid);                                                                                 \
       sb.issue(_b + A_TILE_BYTES, wid);                                                                  \
     } else {                                                                                             \
@@ -331,18 +296,14 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
       sb.issue_tail(_b + A_TILE_BYTES, k_end, zeros, wid, lane);                                         \
     }                                                                                                    \
   } while (0)
-  // Per k-step: counted vmcnt (stage s landed; s+1, s+2 may still fly) -> s_barrier -> DMA for s+3 ->
-  // ds_read fragments -> 16 MFMAs.  With 2 workgroups per CU the other workgroup's waves fill the
-  // SIMD while this one waits.  (A register-double-buffered variant that read step s+1's fragments
-  // under step s's MFMAs measured no faster on MI355X - LDS bandwidth, not latency, is the co-limit.)
-#if VG_ASM_READS
+  // Per k-step: counted vmcnt (stage s landed, later stages may still fly) -> s_barrier -> DMA for stage s+NSTAGE-1
+  // -> ds_read fragments -> 16 MFMAs.  The co-resident workgroups' waves fill the SIMD while this one waits.
   const unsigned smem_base = (unsigned)(unsigned long)(lptr_t)smem;
   FragAddr<A_TR> fra;
   FragAddr<B_TR> frb;
   fra.setup(0, wm * 64, lane);
   frb.setup(A_TILE_BYTES, wn * 64, lane);
-#endif
-  constexpr int DPS = (4 * WM + 8) * VG_BKS / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4), x VG_BKS
+  constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
   STAMP(1);
   for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
   STAMP(2);
@@ -356,34 +317,14 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
     if (s == 0) STAMP(3);
 #endif
     constexpr int dbg = VG_ABLATE;  // timing experiments only (make abl): 1 = no DMA, 2 = no LDS reads, 4 = no MFMA
-#if !VG_ISSUE_LATE
     if (s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
-#endif
-    const unsigned char* cur = smem + (s % NSTAGE) * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < VG_BKS; ++ks) {
     bf16x8 fm[4], fn[4];
     if (dbg & 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { for (int j = 0; j < 8; ++j) { fm[i][j] = (bf16)(float)(s + i); fn[i][j] = (bf16)(float)(lane + i); } }
-    } else
-    {
-#if VG_ASM_READS
+    } else {
       load_frags_asm<A_TR, B_TR>(smem_base + (s % NSTAGE) * STAGE_BYTES, fra, frb, fm, fn);
-#else
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fm[i] = load_frag<A_TR>(cur, wm * 64 + i * 16, lane, ks);
-        fn[i] = load_frag<B_TR>(cur + A_TILE_BYTES, wn * 64 + i * 16, lane, ks);
-      }
-#endif
     }
-#if VG_ISSUE_LATE
-    // The compiler cannot tell the LDS-DMA's destination from the stage being read and puts s_waitcnt vmcnt(0) in
-    // front of the first ds_read that follows a DMA in program order: issuing the next stage AFTER this step's
-    // fragment reads keeps that wait from draining the prefetch (it then lands under this step's MFMAs).
-    if (ks == VG_BKS - 1 && s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
-#endif
     if (dbg & 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)fm[i][0]; acc[0][i][1] += (float)fn[i][1]; }
@@ -398,18 +339,13 @@ __global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 :
         for (int mt = 0; mt < 4; ++mt) accb[mt] = vg_mfma(ones, fm[mt], accb[mt]);
       }
     }
-    }
   }
 #undef ISSUE
 
   // ---- epilogue ---------------------------------------------------------------------------
-  // Accumulators (lane = one row, 4 consecutive n per tile) are transposed through a PRIVATE per-wave
-  // LDS region (32 rows x 64 fp32, 272-B row pitch: conflict-free 16-B writes) so that each lane
-  // then owns 8 consecutive columns of one row and every global access is 16 B per lane with
-  // whole 128-B lines per wave-instruction (per-lane stores at a row stride are issue-bound).
-  // Problem fields are copied to registers first (a reference into kernarg memory is re-read after
-  // every store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt
-  // retires in order, so a load issued behind stores would wait for them.
+  // Problem fields were copied to registers up front (a reference into kernarg memory is re-read after every
+  // store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt retires in order, so a
+  // load issued behind stores would wait for them.
   if (MODE == VG_TN && do_cs && g == 0) {
     float* cs = P.colsum + (size_t)split * P.colsum_split_stride;
 #pragma unroll
@@ -602,9 +538,9 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + BN - 1) / BN;
     int splits = (mode == VG_TN) ? (p.splits > 0 ? p.splits : 1) : 1;
-    int ksteps = (p.K + BKS - 1) / BKS;
+    int ksteps = (p.K + BK - 1) / BK;
     int per = (ksteps + splits - 1) / splits;
-    p.k_per_split = per * BKS;
+    p.k_per_split = per * BK;
     splits = (ksteps + per - 1) / per;  // drop empty slices
     p.splits = splits;
     if (dbg_nostore && mode != VG_TN) { p.C = nullptr; p.C2 = nullptr; p.pre_f32 = 0; }
