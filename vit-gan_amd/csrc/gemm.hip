@@ -510,9 +510,9 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;  // tuning aid
     if (t4 < t4min || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
   }
-  if (const char* e = getenv("VG_GEMM_WM")) wm4 = (atoi(e) == 4) && mode != VG_TN;
+  static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // tuning aid: force the tile height
+  if (wm_env) wm4 = (wm_env == 4) && mode != VG_TN;
   const int bm = wm4 ? 256 : 128;
-  static const bool dbg_nostore = getenv("VG_GEMM_DEBUG_NOSTORE") != nullptr;  // timing experiments only
   VgGemmGroup grp;
   grp.n = n;
 #ifdef VG_STAMPS
@@ -543,7 +543,6 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     p.k_per_split = per * BK;
     splits = (ksteps + per - 1) / per;  // drop empty slices
     p.splits = splits;
-    if (dbg_nostore && mode != VG_TN) { p.C = nullptr; p.C2 = nullptr; p.pre_f32 = 0; }
     p.tile_start = total;
     total += p.tiles_m * p.tiles_n * splits;
     grp.p[i] = p;
