@@ -6,7 +6,18 @@
 // bitwise reproducible run to run.
 #include "vg_common.h"
 
+// Lanes per row of the backward kernels: 32 = 8-byte accesses but half the per-lane state of 16 (the three column
+// accumulators, x_hat and dy*gamma all scale with the columns a lane owns): LayerNorm 210 -> 126 registers (2 -> 4
+// waves/SIMD, 22.3 -> 20.3 us), SLN > 256 -> 180 registers (25.6 -> 17.5 us).  The forward kernels keep 16.
+#ifndef LN_BWD_LPR
+#define LN_BWD_LPR 32
+#endif
+#ifndef SLN_BWD_LPR
+#define SLN_BWD_LPR 32
+#endif
+#ifndef LN_MAX_PARTS
 #define LN_MAX_PARTS 512    // partial rows written by the backward kernels (fixed upper bound)
+#endif
 
 // Thread layout of every kernel below: a wave handles 4 rows at a time, 16 lanes per row; lane `sub` of a
 // row owns the 16-byte chunks sub, sub+16, ... (NV = E/128 chunks of 8 bf16), so each wave-instruction
@@ -362,7 +373,7 @@ int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const flo
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
                      float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 1024 || R < 1) return -3;
-#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, 16>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
+#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, LN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
                      (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep)
   NV_SWITCH(E, LN_BWD)
@@ -374,7 +385,7 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
                       bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 1024 || R < 1) return -3;
-#define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_, 16>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
+#define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_, SLN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
                      rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, dhm, dthr, dkey, dscale, dstep)
   NV_SWITCH(E, SLN_BWD)
 #undef SLN_BWD
