@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 2
+#define VG_ABI_VERSION 3
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -218,6 +218,9 @@ typedef struct VgGenNet {
   float dropout_p;
   unsigned long long dropout_seed;
   const unsigned* dropout_step;
+  /* Optional Fourier positional input of the SIREN (named by BASELINE.json's north_star; NOT in the reference):
+   * fp32 [T, E] table added to the final SLN output of every image before output_network.0.  NULL = reference. */
+  const float* pos_table;
 } VgGenNet;
 /* z fp32 [B,Z]; img bf16 [B, T*CW]: the flat view of generator.py:66-68 (patch == 0) or NCHW [B,C,IH,IH] (patch > 0). */
 int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream);

@@ -120,9 +120,28 @@ def siren(state: Mapping[str, Tensor], base: str, x: Tensor, omega0: float) -> T
     return torch.sin(omega0 * F.linear(x, state[base + "linear.weight"], state[base + "linear.bias"]))
 
 
+def fourier_position_table(d: GenDims) -> Tensor:
+    """Optional Fourier positional input of the SIREN (named by north_star, ABSENT from the reference: parity unpinned;
+    this function is the definition).  [T, E] table: token t sits at (x, y) in [0,1)^2 - its patch-grid cell centre
+    (patch > 0) or (0.5, row centre) for the v1 row tokens - and column e = 4*j + c holds
+    (sin, cos)(2 pi f_j x), (sin, cos)(2 pi f_j y) for c = 0..3 with E/4 log-spaced frequencies f_j from 1 to side/2."""
+    T, E = d.tokens, d.embed
+    side = d.image // d.patch if d.patch else d.tokens
+    t = torch.arange(T, dtype=torch.float64)
+    if d.patch:
+        x, y = ((t % side) + 0.5) / side, (torch.div(t, side, rounding_mode="floor") + 0.5) / side
+    else:
+        x, y = torch.full((T,), 0.5, dtype=torch.float64), (t + 0.5) / side
+    nb = E // 4
+    f = torch.pow(torch.tensor(max(side / 2.0, 1.0), dtype=torch.float64), torch.arange(nb, dtype=torch.float64) / max(nb - 1, 1))
+    ax, ay = 2 * math.pi * x[:, None] * f[None, :], 2 * math.pi * y[:, None] * f[None, :]
+    return torch.stack([torch.sin(ax), torch.cos(ax), torch.sin(ay), torch.cos(ay)], dim=-1).reshape(T, E).float()
+
+
 def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Optional[dict] = None,
-                masks: Optional[Mapping] = None) -> Tensor:
-    """Generator.forward, src/v1/generator.py:58-69."""
+                masks: Optional[Mapping] = None, pos_table: Optional[Tensor] = None) -> Tensor:
+    """Generator.forward, src/v1/generator.py:58-69.  pos_table: the optional Fourier positional input (not in the
+    reference), added to the final SLN output."""
     B = z.shape[0]
     w = F.linear(z, state["mapping_mlp.model.0.0.weight"], state["mapping_mlp.model.0.0.bias"])
     w = w.view(B, d.tokens, d.embed)  # (:59-61)
@@ -137,6 +156,8 @@ def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, taps: Option
         if taps is not None:
             taps["blocks"].append(h)
     y = sln(state, "sln.", h, w)  # (:65)
+    if pos_table is not None:
+        y = y + pos_table
     y = siren(state, "output_network.0.", y, d.omega0)
     y = siren(state, "output_network.1.", y, d.omega0)  # [B, T, C*IW]
     if d.patch:  # patch-grid variant: token t = (gy, gx) carries one C x P x P patch in (c, py, px) order

@@ -168,3 +168,37 @@ def test_patch_grid_generator_module_and_geometry_checks():
     bad = _lib.VgGenDims(128, 60, 256, 4, 1, 128, 192, 30.0, 8, 3, 64)  # 60 tokens is not the 8x8 grid
     lay = _lib.VgGenLayout()
     assert _lib.lib().vg_gen_layout(C_.byref(bad), C_.byref(lay)) != 0
+
+
+@pytest.mark.parametrize("patch", [0, 4])
+def test_generator_with_fourier_position_input(patch):
+    """Optional Fourier positional input of the SIREN (north_star; not in the reference, the oracle defines it): module
+    forward / backward against the oracle, the state_dict unchanged, product and oracle tables identical."""
+    import vit_gan_amd  # noqa: F401
+    import gpu_util as u
+    from weights import make_input
+    from oracle import gen_oracle as go
+    from vit_gan_amd.generator import SirenGenerator, fourier_position_table
+
+    T = 64 if patch else 32
+    d = go.GenDims(latent=128, tokens=T, embed=256, heads=4, layers=1, siren_hidden=128, channels=3, image=32, patch=patch)
+    tab = go.fourier_position_table(d)
+    assert tab.shape == (T, 256) and torch.equal(tab, fourier_position_table(T, 256, 32, patch))
+    G = SirenGenerator(latent=128, image_size=32, channels=3, embed=256, heads=4, layers=1, siren_hidden=128, dropout=0.0,
+                       patch_size=patch, fourier_features=True)
+    plain = SirenGenerator(latent=128, image_size=32, channels=3, embed=256, heads=4, layers=1, siren_hidden=128, dropout=0.0, patch_size=patch)
+    assert list(G.state_dict()) == list(plain.state_dict())
+    st = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    G = G.cuda()
+    z = torch.from_numpy(make_input((3, 128), 8))
+    ref = go.gen_forward(st, z, d, pos_table=tab)
+    R = torch.from_numpy(make_input(tuple(ref.shape), 9))
+    (ref * R).sum().backward()
+    out = G(z.cuda())
+    u.assert_close(out, ref, 0.08, "image")
+    no_table = go.gen_forward({k: v.detach() for k, v in st.items()}, z, d)
+    assert float((ref.detach() - no_table).abs().max()) > 0.1  # the table matters
+    (out * R.cuda()).sum().backward()
+    got = dict(G.named_parameters())
+    for k in ("output_network.0.linear.weight", "transformer_layers.0.mlp.model.0.0.weight", "embedding", "mapping_mlp.model.0.0.bias"):
+        u.assert_close(got[k].grad, st[k].grad, 0.12, f"grad {k}", floor=1e-4)

@@ -46,7 +46,7 @@ class VgGenLayout(C.Structure):
 
 class VgGenNet(C.Structure):
     _fields_ = [("d", VgGenDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
-                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p)]
+                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("pos_table", c_void_p)]
 
 
 P = c_void_p
@@ -116,7 +116,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.vg_abi_version() != 2:
+        if handle.vg_abi_version() != 3:
             raise RuntimeError("libvitgan_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -308,6 +308,20 @@ __global__ __launch_bounds__(256) void vg_sin_grad_kernel(const bf16* __restrict
   *(bf16x4*)(dz + i4) = o;
 }
 
+// x[r, :] += table[r % period, :]   (bf16 rows, fp32 table): the generator's optional Fourier position signal
+__global__ __launch_bounds__(256) void vg_add_table_kernel(bf16* __restrict__ x, const float* __restrict__ table, long long n, int E,
+                                                           int period) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const long long r = i4 / E;
+  const int c = (int)(i4 - r * E);
+  const f32x4 t = *(const f32x4*)(table + (size_t)(r % period) * E + c);
+  bf16x4 v = *(bf16x4*)(x + i4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = vg_f2bf(vg_bf2f(v[j]) + t[j]);
+  *(bf16x4*)(x + i4) = v;
+}
+
 // --------------------------------------- launchers ---------------------------------------------
 static inline unsigned nblk(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
@@ -444,6 +458,12 @@ int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_
 int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st) {
   if (n & 3) return -3;
   hipLaunchKernelGGL(vg_slab_reduce_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, slab, stride, nslab, dst, n, accumulate);
+  return (int)hipGetLastError();
+}
+int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st) {
+  if ((E & 3) || period < 1) return -3;
+  const long long n = rows * E;
+  hipLaunchKernelGGL(vg_add_table_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, x, table, n, E, period);
   return (int)hipGetLastError();
 }
 int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st) {

@@ -564,6 +564,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
                            R, E, 1e-5f, st));
+  if (net->pos_table) VG_TRY(vg_add_table_launch(w.sf, net->pos_table, R, E, T, st));  // constant: the backward is unchanged
   VG_TRY(lin_fwd(w.sf, E, Pb + lay.s1_w, P + lay.s1_b, w.y1, R, d.O, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf1, st));
   bf16* rows = d.patch > 0 ? w.y2 : (bf16*)img;
   VG_TRY(lin_fwd(w.y1, d.O, Pb + lay.s2_w, P + lay.s2_b, rows, R, d.CW, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf2, st));

@@ -58,3 +58,4 @@ int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, fl
     if (_rc != 0) return _rc;   \
   } while (0)
 int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, float* scratch, hipStream_t st);
+int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st);

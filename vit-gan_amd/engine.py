@@ -98,7 +98,9 @@ class GanEngine:
         step_ptr = self.step_t.data_ptr()
         mk = lambda i: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(),  # noqa: E731
                                      self.p_d, self.seed * 8 + i, step_ptr, self.ctx)
-        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr)
+        tab = self.gen.fourier_table
+        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr,
+                           None if tab is None else tab.data_ptr())
         return (mk(0), mk(1), mk(2)), ng
 
     def _d_backward(self, nd, n_img: int, dl, want_w: int, dimg, st) -> None:

@@ -77,9 +77,24 @@ class _GenFn(torch.autograd.Function):
         return None, None, None, None
 
 
+def fourier_position_table(T: int, E: int, image_size: int, patch_size: int) -> torch.Tensor:
+    """[T, E] fp32: token t at (x, y) in [0,1)^2 (patch-grid cell centre, or (0.5, row centre) for the v1 row tokens);
+    column 4*j + c = (sin, cos)(2 pi f_j x), (sin, cos)(2 pi f_j y), E/4 log-spaced frequencies from 1 to side/2."""
+    side = image_size // patch_size if patch_size else T
+    t = torch.arange(T, dtype=torch.float64)
+    if patch_size:
+        x, y = ((t % side) + 0.5) / side, (torch.div(t, side, rounding_mode="floor") + 0.5) / side
+    else:
+        x, y = torch.full((T,), 0.5, dtype=torch.float64), (t + 0.5) / side
+    nb = E // 4
+    f = torch.pow(torch.tensor(max(side / 2.0, 1.0), dtype=torch.float64), torch.arange(nb, dtype=torch.float64) / max(nb - 1, 1))
+    ax, ay = 2 * math.pi * x[:, None] * f[None, :], 2 * math.pi * y[:, None] * f[None, :]
+    return torch.stack([torch.sin(ax), torch.cos(ax), torch.sin(ay), torch.cos(ay)], dim=-1).reshape(T, E).float().contiguous()
+
+
 class SirenGenerator(nn.Module):
     def __init__(self, latent=1024, image_size=32, channels=3, embed=384, heads=4, layers=4, siren_hidden=768,
-                 omega_0=30.0, out_dtype=torch.float32, dropout=0.2, patch_size=0):
+                 omega_0=30.0, out_dtype=torch.float32, dropout=0.2, patch_size=0, fourier_features=False):
         """``patch_size == 0`` (default): the reference's v1 generator - one token per image row, each emitting
         ``channels * image_size`` values, assembled by a flat ``view`` (src/v1/generator.py:19,25,51,66-68).
         ``patch_size > 0`` (not in the reference): the same blocks on the discriminator's patch
@@ -94,6 +109,10 @@ class SirenGenerator(nn.Module):
         else:
             T, out_features = image_size, channels * image_size
         self.patch_size = int(patch_size)
+        # optional Fourier positional input of the SIREN (north_star; not in the reference): a fixed [T, E] table added to
+        # the final SLN output.  A non-persistent buffer: the state_dict stays the reference's.
+        self.register_buffer("fourier_table", fourier_position_table(T, E, image_size, self.patch_size) if fourier_features else None,
+                             persistent=False)
         self.latent, self.image_size, self.channels, self.out_dtype = latent, image_size, channels, out_dtype
         self.dropout_p = float(dropout)  # attention_dropout_rate = mlp_dropout = 0.2 in src/v1/config.py:36,39
         self.mapping_mlp = _mlp_holder(T * E, latent)
@@ -169,7 +188,9 @@ class SirenGenerator(nn.Module):
 
     def _net(self, drop=(0.0, 0)):
         fp = self._flat
-        return _lib.VgGenNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr(), float(drop[0]), int(drop[1]), None)
+        tab = self.fourier_table
+        return _lib.VgGenNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr(), float(drop[0]), int(drop[1]), None,
+                             None if tab is None else tab.data_ptr())
 
     def forward(self, z):
         if not z.is_cuda:
