@@ -204,8 +204,17 @@ enum { F_RES = 1, F_RESF = 2, F_REMAP = 4, F_C2 = 8, F_PREF32 = 16, F_ALL = 31, 
 // Occupancy is the lever on MI355X for these short-K GEMMs (measured: 16 waves/CU beats a deeper DMA ring at
 // 8-12 waves/CU by 25-40 %): WM=2 -> 2-stage ring (32 KiB) x 4 workgroups/CU, WM=4 -> 3-stage ring (72 KiB) x 2
 // workgroups/CU; both 4 waves/SIMD, so at most 128 registers per lane.
+// Waves per SIMD the kernel is compiled for: 4 (<= 128 registers) for the hot instantiations, 3 for weight gradients
+// (LDS allows 3 workgroups/CU anyway), 2 (<= 256 registers) for the feature-laden epilogues of the rarely launched
+// embedding / generator-entry / SIREN GEMMs, which otherwise spill 50-120 registers to scratch.
 template <int MODE, int WM, int ACT, int FEAT>
-__global__ __launch_bounds__(128 * WM, (MODE == VG_TN ? 3 : (WM == 2 ? OCC_WM2 : OCC_WM4))) void vg_gemm_kernel(const VgGemmGroup grp) {
+constexpr int vg_gemm_waves() {
+  if (MODE == VG_TN) return 3;
+  if ((FEAT & (F_RESF | F_REMAP | F_PREF32)) || ACT == VG_ACT_MUL_COS) return 2;
+  return WM == 2 ? OCC_WM2 : OCC_WM4;
+}
+template <int MODE, int WM, int ACT, int FEAT>
+__global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) void vg_gemm_kernel(const VgGemmGroup grp) {
   constexpr int NW = 2 * WM;
   constexpr bool A_TR = (MODE == VG_TN);
   constexpr bool B_TR = (MODE != VG_NT);
