@@ -92,44 +92,60 @@ __global__ __launch_bounds__(256) void vg_scatter_cls_kernel(const bf16* __restr
   if (s == 0) v = *(const u32x4*)(src + (size_t)b * E + 8 * c);
   *(u32x4*)(g + (size_t)r * E + 8 * c) = v;
 }
-// out[s, e] = sum_b g[(b*S + s), e]   (fp32; 32 column pairs x 8 batch-lanes per workgroup, fixed fold order)
+// out[s, e] = sum_b g[(b*S + s), e]   (fp32).  A workgroup owns 64 consecutive columns of one token row (a whole
+// 128-B line per batch item) x 32 batch lanes: 16-byte loads, 4 independent loads in flight per thread, and a
+// fixed-order fold of the 32 batch lanes through LDS (deterministic).
 __global__ __launch_bounds__(256) void vg_batch_sum_kernel(const bf16* __restrict__ g, float* __restrict__ out, int B, int S,
                                                            int E) {
-  __shared__ float red[8][66];
-  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl;  // column-pair index over S*E/2
-  const int total = S * (E / 2);
-  float a0 = 0.f, a1 = 0.f;
-  int s = 0, e = 0;
-  if (i < total) {
-    s = i / (E / 2); e = 2 * (i - s * (E / 2));
-    for (int b = bl; b < B; b += 8) {
-      const bf16x2 t = *(const bf16x2*)(g + ((size_t)b * S + s) * E + e);
-      a0 += vg_bf2f(t[0]); a1 += vg_bf2f(t[1]);
-    }
-  }
-  red[bl][2 * cl] = a0; red[bl][2 * cl + 1] = a1;
-  __syncthreads();
-  if (bl != 0 || i >= total) return;
-  float r0 = 0.f, r1 = 0.f;
+  __shared__ float red[32][65];
+  const int cl = threadIdx.x & 7, bl = threadIdx.x >> 3;     // 8 chunks of 8 columns, 32 batch lanes
+  const int chunks = E / 64;                                  // 64-column groups per row
+  const int s = blockIdx.x / chunks, e0 = (blockIdx.x - s * chunks) * 64 + 8 * cl;
+  float a[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { r0 += red[k][2 * cl]; r1 += red[k][2 * cl + 1]; }
-  out[(size_t)s * E + e] = r0; out[(size_t)s * E + e + 1] = r1;
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  const bf16* p = g + (size_t)s * E + e0;
+  const size_t bstride = (size_t)S * E;
+  int b = bl;
+  for (; b + 96 < B; b += 128) {
+    bf16x8 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = *(const bf16x8*)(p + (size_t)(b + 32 * u) * bstride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += vg_bf2f(t[u][j]);
+  }
+  for (; b < B; b += 32) {
+    const bf16x8 t = *(const bf16x8*)(p + (size_t)b * bstride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += vg_bf2f(t[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[bl][8 * cl + j] = a[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r += red[k][threadIdx.x];
+    out[(size_t)s * E + (blockIdx.x - s * chunks) * 64 + threadIdx.x] = r;
+  }
 }
 // embed grads from tok_sum [S,E]: d_cls += tok_sum[0]; d_pos += tok_sum[1:]; d_convbias += sum_n tok_sum[1+n]
+// One thread per (token, column) for the elementwise part; the first E threads also fold the conv-bias column sums.
 __global__ __launch_bounds__(256) void vg_embed_small_grads_kernel(const float* __restrict__ tok_sum, float* __restrict__ d_cls,
                                                                    float* __restrict__ d_pos, float* __restrict__ d_bias, int S,
                                                                    int E) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
-  d_cls[e] += tok_sum[e];
-  float a = 0.f;
-  for (int n = 1; n < S; ++n) {
-    const float t = tok_sum[(size_t)n * E + e];
-    d_pos[(size_t)(n - 1) * E + e] += t;
-    a += t;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * E) return;
+  const float t = tok_sum[i];
+  if (i < E) d_cls[i] += t; else d_pos[i - E] += t;
+  if (i < E) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int n = 1; n < S; ++n) a += tok_sum[(size_t)n * E + i];
+    d_bias[i] += a;
   }
-  d_bias[e] += a;
 }
 
 // ---- classifier tail: logits[b,k] = t[b,:] . W2[k,:] + b2[k]   (one wave per (b,k)) -------------
@@ -419,11 +435,12 @@ int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStre
   return (int)hipGetLastError();
 }
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st) {
-  hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(nblk((long long)S * (E / 2), 32)), dim3(256), 0, st, g, out, B, S, E);
+  if (E & 63) return -3;
+  hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(S * (E / 64)), dim3(256), 0, st, g, out, B, S, E);
   return (int)hipGetLastError();
 }
 int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st) {
-  hipLaunchKernelGGL(vg_embed_small_grads_kernel, dim3(nblk(E)), dim3(256), 0, st, tok_sum, d_cls, d_pos, d_bias, S, E);
+  hipLaunchKernelGGL(vg_embed_small_grads_kernel, dim3(nblk((long long)S * E)), dim3(256), 0, st, tok_sum, d_cls, d_pos, d_bias, S, E);
   return (int)hipGetLastError();
 }
 int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* logits, int B, int E, int Kc, hipStream_t st) {
