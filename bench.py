@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
     ap.add_argument("--roofline-only", action="store_true", help="profiling aid: run only the dominant-kernel timing leg and print its object")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the default and the measured path); gloo only to rehearse the multi-rank code path on a box "
+                         "with fewer GPUs than ranks (ranks then share devices: local_rank %% device_count)")
     args = ap.parse_args()
     if args.roofline_only:
         import torch
@@ -144,10 +147,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
     geo = {"c2": dict(image=32, patch=4, embed=384, heads=4, batch=256, gpatch=0),
@@ -219,7 +227,7 @@ def main():
                                     "c5": "C5 shape: 3x128x128, patch 16 (65 tokens), E=768, 12 heads, 6 blocks ViT discriminator + patch-grid "
                                           "SLN/SIREN generator (64 tokens), bf16 attention, full alternating G+D step, AdamW"}[args.workload],
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
-                       "parallelism": f"dp{world}", "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
+                       "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
             "roofline": roof,
         }
