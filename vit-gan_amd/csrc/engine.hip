@@ -507,7 +507,6 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
   w.emb_sum = c.take<float>(T * E);
   long long slab = GEN_SPLIT_CAP * lay.layer_weights;
-  if (T * E * d.Z > slab) slab = T * E * d.Z;
   if (GEN_SPLIT_CAP * (long long)d.O * E > slab) slab = GEN_SPLIT_CAP * (long long)d.O * E;
   w.slab = c.take<float>(slab);
   return c.off;
@@ -668,9 +667,10 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   VG_TRY(vg_colsum_f32_launch(w.dw_acc, B, T * E, G + lay.map_b, T * E, nullptr, 0, nullptr, 0, nullptr, 0, 1, st));
   VG_TRY(vg_cast_f32_bf16_launch(w.dw_acc, w.dwb, (long long)R * E, st));
   {
-    VgGemmProb p = wg(w.dwb, T * E, w.zb, d.Z, B, w.slab, (long long)T * E * d.Z, 1);
+    // K = B rows only: one K slice, accumulated straight into the gradient buffer (a 50 MB slab and its fold pass saved)
+    VgGemmProb p = wg(w.dwb, T * E, w.zb, d.Z, B, G + lay.map_w, 0, 1);
+    p.cf_accumulate = 1;
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
-    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)T * E * d.Z, p.splits, G + lay.map_w, (long long)T * E * d.Z, 1, st));
   }
   return 0;
 }

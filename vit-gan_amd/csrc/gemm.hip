@@ -431,6 +431,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       if (m >= eM || !ncol_ok) continue;
       if (MODE == VG_TN) {
         float* dst = eCf + (size_t)split * ecfs + (unsigned)(m * eldcf + n);
+        if (P.cf_accumulate) { lo += *(const f32x4*)dst; hi += *(const f32x4*)(dst + 4); }
         *(f32x4*)dst = lo;
         *(f32x4*)(dst + 4) = hi;
         continue;
@@ -552,6 +553,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     p.k_per_split = per * BK;
     splits = (ksteps + per - 1) / per;  // drop empty slices
     p.splits = splits;
+    if (p.cf_accumulate && (mode != VG_TN || splits != 1)) return -4;  // accumulation needs a single writer per element
     p.tile_start = total;
     total += p.tiles_m * p.tiles_n * splits;
     grp.p[i] = p;

@@ -26,6 +26,7 @@ struct VgGemmProb {
   bf16* C; int ldc;            // bf16 result (nullable)
   float* Cf; int ldcf;         // fp32 result: TN slabs, or fp32 pre-activation copy when pre_f32
   long long cf_split_stride;
+  int cf_accumulate;           // TN with ONE K slice: Cf += result (the gradient buffer itself; no slab, no fold pass)
   bf16* C2; int ldc2;          // bf16 pre-activation copy (nullable)
   const float* bias;           // [N] fp32 (nullable)
   const bf16* res; int ldr;    // residual added after the activation (nullable)
