@@ -125,6 +125,12 @@ int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int
 int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const int* step_dev, float gscale, void* stream);
+/* diversity_loss of the reference's unreached generator step (src/v2/utils.py:147-152; training.py:73-74 adds 0.1 x it
+ * to the generator loss): loss_out[0] = sum_{i,j} |x_i - x_j|_1 / (B (B-1)) over images bf16 [B, D]; when d_images is
+ * not NULL, d_images (bf16 [B, D]) += weight * d loss / d images.  scratch: ceil(D/16) floats.  B <= 1024. */
+int vg_diversity_loss(const void* images, void* d_images, float* loss_out, float* scratch, int B, int D,
+                      float weight, void* stream);
+
 /* torch.nn.utils.clip_grad_norm_ (the reference's Wasserstein step, src/v2/training.py:78,104) on a flat fp32 gradient
  * buffer: g *= min(1, max_norm / (gscale*|g|_2 + 1e-6)) in place; scratch: 1 + 1024 floats of device memory,
  * scratch[0] receives gscale*|g|_2.  Deterministic (no atomics).  n % 4 == 0. */

@@ -52,6 +52,13 @@ def g_loss(logits: Tensor, kind: str) -> Tensor:
     raise ValueError(kind)
 
 
+def diversity_loss(fake: Tensor) -> Tensor:
+    """src/v2/utils.py:147-152: sum of all pairwise L1 distances between the flattened images / (B (B-1))."""
+    B = fake.shape[0]
+    flat = fake.reshape(B, -1)
+    return torch.cdist(flat, flat, p=1).sum() / (B * (B - 1))
+
+
 class GanStepOracle:
     """Holds leaf tensors for D (v2 ViT) and G (v1 SLN/SIREN) and runs reference steps."""
 
@@ -60,6 +67,7 @@ class GanStepOracle:
                  weight_decay: float = 1e-3, loss: str = "ns", clip_d: float = None, clip_g: float = None):
         self.ddims, self.gdims, self.loss = ddims, gdims, loss
         self.clip_d, self.clip_g = clip_d, clip_g  # utils.clip_grad_norm_ max norms (training.py:78,104), None = off
+        self.diversity_weight = 0.0                # weight of diversity_loss(fake) in the G loss (0.1 at training.py:73-74)
         self.d = {k: v.detach().clone().float().requires_grad_(True) for k, v in d_state.items()}
         self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
         self.opt_d = torch.optim.AdamW(list(self.d.values()), lr=lr_d, weight_decay=weight_decay)
@@ -85,7 +93,8 @@ class GanStepOracle:
         for p in self.g.values():
             p.grad = None
         loss_g = g_loss(self.D(fake), self.loss)
-        loss_g.backward()
+        total_g = loss_g + self.diversity_weight * diversity_loss(fake) if self.diversity_weight else loss_g
+        total_g.backward()
         if self.clip_g is not None:
             torch.nn.utils.clip_grad_norm_(list(self.g.values()), max_norm=self.clip_g)
         self.opt_g.step()

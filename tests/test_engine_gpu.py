@@ -247,7 +247,8 @@ def test_wasserstein_losses_and_gradient_clipping():
     B = 8
     D, G, oracle = _build(B, "wasserstein")
     oracle.clip_d, oracle.clip_g = 0.05, 0.02
-    eng = GanEngine(D, G, batch=B, loss="wasserstein", clip_d=0.05, clip_g=0.02)
+    oracle.diversity_weight = 0.1
+    eng = GanEngine(D, G, batch=B, loss="wasserstein", clip_d=0.05, clip_g=0.02, diversity_weight=0.1)
     g = torch.Generator().manual_seed(0)
     real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
     w_before = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
@@ -257,6 +258,10 @@ def test_wasserstein_losses_and_gradient_clipping():
     got = losses.cpu().tolist()
     assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)
     # the recorded norms are the pre-clip global norms and exceed the limits (clipping was active)
+    from oracle.step_oracle import diversity_loss
+    with torch.no_grad():
+        want_div = float(diversity_loss(oracle.G(eng.z.detach().cpu())))  # oracle G was already stepped: compare loosely
+    assert abs(float(eng.div_loss) - want_div) < 0.15 * abs(want_div) + 1e-3
     nd, ng = float(eng.clip_scratch[0, 0]), float(eng.clip_scratch[1, 0])
     assert nd > 0.05 and ng > 0.02, (nd, ng)
     k = "vit.encoder.1.fc2.weight"

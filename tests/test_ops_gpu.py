@@ -275,3 +275,24 @@ def test_wasserstein_loss_kind():
         u.sync()
         assert abs(float(lo) - float(want)) < 1e-6
         assert torch.allclose(dl.cpu(), torch.full((37,), dw / 37))
+
+
+@pytest.mark.parametrize("B,D", [(8, 48), (64, 3072), (256, 100)])
+def test_diversity_loss_matches_torch(B, D):
+    """vg_diversity_loss vs torch.cdist(p=1) (src/v2/utils.py:147-152): loss within 1e-4 relative; gradient (added onto an
+    existing bf16 gradient) within 2^-7 of max|ref|."""
+    import gpu_util as u
+    g = torch.Generator().manual_seed(B + D)
+    x = torch.randn(B, D, generator=g).to(torch.bfloat16)
+    d0 = (torch.randn(B, D, generator=g) * 1e-3).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    ref = torch.cdist(xr, xr, p=1).sum() / (B * (B - 1))
+    ref.backward()
+    w = 0.1
+    xd, dd = u.dev(x), u.dev(d0)
+    lo = torch.empty(1, device="cuda")
+    scratch = torch.zeros((D + 15) // 16, device="cuda")
+    u.call("vg_diversity_loss", u.ptr(xd), u.ptr(dd), u.ptr(lo), u.ptr(scratch), B, D, C.c_float(w), u.stream())
+    u.sync()
+    assert abs(float(lo) - float(ref)) <= 1e-4 * float(ref)
+    u.assert_close(dd, d0.float() + w * xr.grad, 2.0 ** -7, "d images")

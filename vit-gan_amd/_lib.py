@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vg_attention_l2_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
+    "vg_diversity_loss": (c_int, [P, P, P, P, c_int, c_int, c_float, P]),
     "vg_grad_clip": (c_int, [P, c_ll, c_float, c_float, P, P]),
     "vg_cast_f32_bf16": (c_int, [P, P, c_ll, P]),
     "vg_ctx_create": (c_int, [C.POINTER(c_void_p)]),

@@ -119,6 +119,11 @@ extern "C" int vg_adamw_step(float* p, const float* g, float* m, float* v, void*
   return vg_adamw_launch(p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, step_dev, gscale,
                          (hipStream_t)stream);
 }
+extern "C" int vg_diversity_loss(const void* images, void* d_images, float* loss_out, float* scratch, int B, int D, float weight,
+                                void* stream) {
+  if (!images || !loss_out || !scratch) return -1;
+  return vg_diversity_launch((const bf16*)images, (bf16*)d_images, loss_out, scratch, B, D, weight, (hipStream_t)stream);
+}
 extern "C" int vg_grad_clip(float* g, long long n, float gscale, float max_norm, float* scratch, void* stream) {
   if (!g || !scratch || n < 1 || !(max_norm > 0.f)) return -1;
   return vg_grad_clip_launch(g, n, gscale, max_norm, scratch, (hipStream_t)stream);

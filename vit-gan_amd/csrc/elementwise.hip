@@ -265,6 +265,61 @@ int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, flo
   return (int)hipGetLastError();
 }
 
+// ---- diversity loss of the reference's unreached generator step (src/v2/utils.py:147-152, training.py:73-74) --------
+// L = sum_{i,j} |x_i - x_j|_1 / (B (B-1)) over the batch of flattened images.  One workgroup per 256 features: the B
+// values of a feature sit in LDS, thread i (feature f, sample b) sums |x_b - x_j| and sign(x_b - x_j) over j:
+//   loss += sum_j |x_b - x_j|;   dL/dx_b[f] = 2 sum_j sign(x_b[f] - x_j[f]) / (B (B-1))  (both orders of a pair count).
+// d_img += weight * dL/dx (bf16), part[block] = partial loss (folded by the caller's second launch: deterministic).
+__global__ __launch_bounds__(256) void vg_diversity_kernel(const bf16* __restrict__ x, bf16* __restrict__ d_img, float* __restrict__ part,
+                                                           int B, int D, float weight) {
+  extern __shared__ float col[];  // [16 features][B]
+  __shared__ float red[4];
+  const int f0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * B; i += 256) {
+    const int f = i & 15, b = i >> 4;
+    col[f * B + b] = (f0 + f < D) ? vg_bf2f(x[(size_t)b * D + f0 + f]) : 0.f;
+  }
+  __syncthreads();
+  float lsum = 0.f;
+  const float inv = 1.0f / ((float)B * (float)(B - 1));
+  for (int i = threadIdx.x; i < 16 * B; i += 256) {
+    const int f = i & 15, b = i >> 4;
+    if (f0 + f >= D) continue;
+    const float v = col[f * B + b];
+    float a = 0.f, sg = 0.f;
+    for (int j = 0; j < B; ++j) {
+      const float d = v - col[f * B + j];
+      a += fabsf(d);
+      sg += (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    }
+    lsum += a;
+    if (d_img) {
+      bf16* g = d_img + (size_t)b * D + f0 + f;
+      *g = vg_f2bf(vg_bf2f(*g) + weight * 2.f * sg * inv);
+    }
+  }
+  lsum = vg_wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
+}
+__global__ __launch_bounds__(256) void vg_fold_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  a = vg_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int vg_diversity_launch(const bf16* x, bf16* d_img, float* loss_out, float* scratch, int B, int D, float weight, hipStream_t st) {
+  if (B < 2 || D < 1 || (size_t)16 * B * 4 > 64 * 1024) return -3;
+  const int nb = (D + 15) / 16;
+  hipLaunchKernelGGL(vg_diversity_kernel, dim3(nb), dim3(256), (size_t)16 * B * 4, st, x, d_img, scratch, B, D, weight);
+  hipLaunchKernelGGL(vg_fold_sum_kernel, dim3(1), dim3(256), 0, st, scratch, nb, loss_out);
+  return (int)hipGetLastError();
+}
+
 // ---- fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics) ----------------------
 // p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps);  shadow = bf16(p).   g is pre-scaled by gscale.

@@ -59,3 +59,4 @@ int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, fl
   } while (0)
 int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, float* scratch, hipStream_t st);
 int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st);
+int vg_diversity_launch(const bf16* x, bf16* d_img, float* loss_out, float* scratch, int B, int D, float weight, hipStream_t st);

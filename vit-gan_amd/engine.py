@@ -39,9 +39,12 @@ class GanEngine:
                  eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
+                 diversity_weight: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
-        Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop)."""
+        Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
+        diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
+        over this rank's batch - under data parallelism it is NOT the global-batch quantity)."""
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
             raise TypeError("GanEngine needs a ViTDiscriminator/VisionTransformer and a SirenGenerator")
@@ -59,6 +62,8 @@ class GanEngine:
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
         self.clip_d, self.clip_g = clip_d, clip_g
+        self.div_w = float(diversity_weight)
+        self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
         self.sync = GradSync(process_group, self.dev, overlap=True)
@@ -74,6 +79,7 @@ class GanEngine:
         self.ws_g = torch.empty(L.vg_gen_ws_bytes(C.byref(g), B), dtype=torch.uint8, device=dev)
         self.imgs = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)  # [real ; fake]
         self.dfake = torch.empty(B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)
+        self.div_scratch = torch.zeros((d.C * d.IH * d.IH + 15) // 16, dtype=torch.float32, device=dev)
         self.logits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
         self.dlogits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
         self.z = torch.empty(B, g.Z, dtype=torch.float32, device=dev)
@@ -170,6 +176,10 @@ class GanEngine:
         _lib.check(L.vg_vit_forward(C.byref(nd_c), B, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
         self._loss(0, B, 2, 2, st)
         _lib.check(L.vg_vit_backward(C.byref(nd_c), B, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st), "vg_vit_backward")
+        if self.div_w != 0.0:  # total_gen_loss = loss + w * diversity_loss(fake_images): its gradient joins dL/d fake
+            Dn = self.dfake[0].numel()
+            _lib.check(L.vg_diversity_loss(fake_ptr, _p(self.dfake), _p(self.div_loss), _p(self.div_scratch), B, Dn, self.div_w, st),
+                       "vg_diversity_loss")
         _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
         self.sync.reduce_range(fg.grad, 0, fg.total)
         self.sync.wait()
