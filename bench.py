@@ -60,6 +60,21 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{_cpu_model()}, os.cpu_count={os.cpu_count()})"}
 
 
+def vit_flops_per_image(image, patch, embed, layers=6, mlp_ratio=2, classes=1, channels=3):
+    """Algorithmic matmul FLOPs of one discriminator forward per image (F_D = 961.72 MFLOP at C2)."""
+    N = (image // patch) ** 2
+    S, E, r = N + 1, embed, mlp_ratio
+    per_layer = 2 * S * E * 3 * E + 2 * S * S * E + 2 * S * S * E + 2 * S * E * E + 2 * (2 * S * E * r * E)
+    return 2 * N * (channels * patch * patch) * E + layers * per_layer + 2 * E * E + 2 * E * classes
+
+
+def gen_flops_per_image(latent, tokens, embed, layers, siren_hidden, out_features):
+    """Algorithmic matmul FLOPs of one generator forward per image (F_G1 = 243.79 MFLOP at the v1 defaults)."""
+    Z, T, E, O = latent, tokens, embed, siren_hidden
+    per_layer = 2 * T * E * 3 * E + 4 * T * T * E + 2 * T * E * E + 2 * T * E * E
+    return 2 * Z * T * E + layers * per_layer + 2 * T * E * O + 2 * T * O * out_features
+
+
 def gemm_roofline(torch, B):
     """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<1, 4, 0, 0>,
     the input-gradient GEMM; timed at its heaviest shape, the QKV dgrad of the fused real+fake pass:
@@ -134,7 +149,6 @@ def main():
     import torch
     import torch.distributed as dist
     import vit_gan_amd  # noqa: F401
-    from oracle import gen_oracle as go, vit_oracle as vo
     from vit_gan_amd.config import Config
     from vit_gan_amd.engine import GanEngine
     from vit_gan_amd.generator import SirenGenerator
@@ -206,10 +220,9 @@ def main():
     ok = all(x == x and abs(x) < 1e4 for x in lv)
 
     if rank == 0:
-        f_d = vo.matmul_flops_per_image(vo.VitDims(image=IMG, patch=geo["patch"], embed=geo["embed"], heads=geo["heads"], classes=1))
+        f_d = vit_flops_per_image(IMG, geo["patch"], geo["embed"])
         gd = G._dims
-        f_g = go.matmul_flops_per_image(go.GenDims(latent=gd.Z, tokens=gd.T, embed=gd.E, heads=gd.H, layers=gd.L, siren_hidden=gd.O,
-                                                    image=IMG, patch=geo["gpatch"]))
+        f_g = gen_flops_per_image(gd.Z, gd.T, gd.E, gd.L, gd.O, gd.CW)
         f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
