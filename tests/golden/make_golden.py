@@ -10,6 +10,9 @@ none of them is touched by the modules exercised here.  Parameters are NOT taken
 from the reference's RNG: tests/golden/weights.py draws them from numpy PCG64
 and they are loaded into the reference modules with load_state_dict(strict=True),
 so a fixture stores only seeds and fingerprints of outputs / gradients.
+Families: vit_*.npz (src/v2 ViT, 5 shapes), vitgen_v2.npz (the v2 generator tail and its exception), gen_*.npz (src/v1
+generator), v1att_*.npz (src/v1 MultiHeadSelfAttention with L2-distance scores, with and without the spectral rescale),
+v1tokens.npz (src/v1 PatchEncoder._get_tokens).
 The reference never travels: only this script and the .npz files are committed.
 """
 from __future__ import annotations
