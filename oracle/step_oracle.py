@@ -98,4 +98,4 @@ class GanStepOracle:
         if self.clip_g is not None:
             torch.nn.utils.clip_grad_norm_(list(self.g.values()), max_norm=self.clip_g)
         self.opt_g.step()
-        return {"d_real": float(loss_real), "d_fake": float(loss_fake), "g": float(loss_g)}
+        return {"d_real": float(loss_real.detach()), "d_fake": float(loss_fake.detach()), "g": float(loss_g.detach())}
