@@ -159,8 +159,10 @@ static void set_drop(VgGemmProb& p, const Drop& d, int site, int post) {
 }
 // forward Linear: C = act(A W^T + b) (+res)
 static int lin_fwd(const bf16* A, int K, const bf16* W, const float* bias, bf16* C, int M, int N, int act, float ascale,
-                   const bf16* res, bf16* pre_bf16, float* pre_f32, hipStream_t st, const Drop* drop = nullptr, int site = 0) {
+                   const bf16* res, bf16* pre_bf16, float* pre_f32, hipStream_t st, const Drop* drop = nullptr, int site = 0,
+                   int c2_gelu_grad = 0) {
   VgGemmProb p = mk(A, K, W, K, M, N, K);
+  p.c2_gelu_grad = c2_gelu_grad;
   if (drop) set_drop(p, *drop, site, 0);
   p.C = C; p.ldc = N; p.bias = bias; p.act = act; p.act_scale = ascale;
   p.res = res; p.ldr = N; p.C2 = pre_bf16; p.ldc2 = N;
@@ -296,7 +298,8 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
     VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
                             w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
-    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st));
+    // z1 keeps gelu'(pre-activation), the only thing the backward needs of it
+    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st, nullptr, 0, 1));
     VG_TRY(lin_fwd(a1, rE, Pb + lo + lay.w2, P + lo + lay.b2, w.X + (size_t)(l + 1) * ME, M, E, VG_ACT_NONE, 0.f, xmid,
                    nullptr, nullptr, st, &dr, 2 + 2 * l));
   }
@@ -373,8 +376,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* g = cur.gin;
     const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
     // ---------------- input-gradient chain (main stream) ----------------
-    // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(z1)   (fused epilogue)
-    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, z1, nullptr, 0.f, st));
+    // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z, z1, nullptr, 0.f, st));
     VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, part2, M, E,
                             drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));

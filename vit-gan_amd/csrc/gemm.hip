@@ -237,7 +237,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   // epilogue operands, read from kernarg memory up front (overlaps the prologue DMA latency)
   const int eM = P.M, eN = P.N;
   bf16* const eC = P.C; const int eldc = P.ldc;
-  bf16* const eC2 = P.C2; const int eldc2 = P.ldc2;
+  bf16* const eC2 = P.C2; const int eldc2 = P.ldc2; const int ec2g = P.c2_gelu_grad;
   float* const eCf = P.Cf; const int eldcf = P.ldcf; const long long ecfs = P.cf_split_stride;
   const float* const ebias = P.bias;
   const bf16* const eres = P.res; const int eldr = P.ldr;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   // through LDS (the LDS transpose of the first version cost ~1.5k LDS cycles per workgroup and stalled the
   // co-resident workgroup's main loop).  8 slots per lane: q = 2*mt + pair.
   STAMP(5);
-  constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD);
+  constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD || ACT == VG_ACT_MUL_Z);
   constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
   constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
   constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0, HAS_DROP = (FEAT & F_DROP) != 0;
@@ -444,7 +444,18 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
         *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
         *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
       }
-      if (HAS_C2 && eC2) {
+      float gact[8];  // GELU: activation and derivative share one exp / rcp / polynomial
+      if (ACT == VG_ACT_GELU) {
+        float gd[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vg_gelu_both(v[r], gact[r], gd[r]);
+        if (HAS_C2 && eC2) {
+          bf16x8 o;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(ec2g ? gd[r] : v[r]);
+          *(bf16x8*)(eC2 + (unsigned)(mo * eldc2 + n)) = o;
+        }
+      } else if (HAS_C2 && eC2) {
         bf16x8 o;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const float zv = vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
-          v[r] *= (ACT == VG_ACT_MUL_GELU_GRAD) ? vg_gelu_grad(zv) : (1.f - zv * zv);
+          v[r] *= (ACT == VG_ACT_MUL_GELU_GRAD) ? vg_gelu_grad(zv) : ((ACT == VG_ACT_MUL_Z) ? zv : (1.f - zv * zv));
         }
       } else if (NEED_ZF) {
 #pragma unroll
@@ -462,6 +473,9 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
           v[r] *= ascale * __cosf(ascale * pre_f0[PRE_F ? q : 0][r]);
           v[r + 4] *= ascale * __cosf(ascale * pre_f1[PRE_F ? q : 0][r]);
         }
+      } else if (ACT == VG_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gact[r];
       } else if (ACT != VG_ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = apply_act<ACT>(ascale, v[r]);
@@ -518,7 +532,8 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   for (int i = 0; i < n; ++i) {
     const long long t4 = (long long)((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
     static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;  // tuning aid
-    if (t4 < t4min || mode == VG_TN || probs[i].act != VG_ACT_NONE) wm4 = 0;
+    const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z;  // no transcendental in the epilogue
+    if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;
   }
   static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // tuning aid: force the tile height
   if (wm_env) wm4 = (wm_env == 4) && mode != VG_TN;
@@ -605,6 +620,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
       case VG_ACT_MUL_GELU_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_GELU_GRAD, 0); break;
       case VG_ACT_MUL_COS: VG_BY_WM(VG_NN, VG_ACT_MUL_COS, 0); break;
       case VG_ACT_MUL_TANH_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_TANH_GRAD, 0); break;
+      case VG_ACT_MUL_Z: VG_BY_WM(VG_NN, VG_ACT_MUL_Z, 0); break;
       default: return -4;
     }
   } else if (mode == VG_TN) {

@@ -67,6 +67,13 @@ __device__ __forceinline__ float vg_gelu_grad(float x) {  // Phi(x) + x * phi(x)
   const float er = copysignf(vg_erf_pos(ax, e), x);
   return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
 }
+__device__ __forceinline__ void vg_gelu_both(float x, float& g, float& dg) {  // gelu(x) and gelu'(x) from one exp / rcp / Horner chain
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-ax * ax);
+  const float phi = 0.5f * (1.0f + copysignf(vg_erf_pos(ax, e), x));
+  g = x * phi;
+  dg = phi + x * 0.39894228040143268f * e;
+}
 __device__ __forceinline__ float vg_tanh(float x) {  // 1 - 2/(exp(2x)+1), saturates cleanly for |x| large
   const float e = __expf(2.0f * x);
   return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
