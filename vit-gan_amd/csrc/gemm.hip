@@ -532,7 +532,8 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   for (int i = 0; i < n; ++i) {
     const long long t4 = (long long)((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
     static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;  // tuning aid
-    const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z;  // no transcendental in the epilogue
+    // epilogues that fit the 128-register budget of 8-wave workgroups (sin / cos / tanh variants do not)
+    const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z || probs[i].act == VG_ACT_GELU;
     if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;
   }
   static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // tuning aid: force the tile height
