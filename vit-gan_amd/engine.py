@@ -62,6 +62,7 @@ class GanEngine:
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
         self.clip_d, self.clip_g = clip_d, clip_g
+        self.dp_chunks = 3  # pieces of the D backward whose gradient exchange overlaps the remaining backward
         self.div_w = float(diversity_weight)
         self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
@@ -110,8 +111,9 @@ class GanEngine:
         return (mk(0), mk(1), mk(2)), ng
 
     def _d_backward(self, nd, n_img: int, dl, want_w: int, dimg, st) -> None:
-        """D backward; under data parallelism in two halves so that the all-reduce of the upper blocks'
-        gradients (a contiguous tail of the flat buffer) overlaps the backward of the lower blocks."""
+        """D backward; under data parallelism in ``dp_chunks`` pieces (head + upper blocks first) so that the all-reduce
+        of each finished piece - a contiguous tail of the flat gradient buffer - overlaps the backward of the blocks
+        below it; only the last piece's exchange is exposed."""
         L = _lib.lib()
         nL = self.vit._dims.L
         if self.world == 1 or not want_w:
@@ -119,12 +121,17 @@ class GanEngine:
             return
         fd = self.vit._flat
         lay = flat.vit_layout(self.vit._dims)
-        half = nL // 2
-        cut = lay.layer0 + (nL - half) * lay.layer_stride  # blocks >= nL-half and the head are final after part 1
-        _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, 0, 1 + half, st), "vg_vit_backward_stages")
-        self.sync.reduce_range(fd.grad, cut, fd.total)
-        _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, 1 + half, nL + 2, st), "vg_vit_backward_stages")
-        self.sync.reduce_range(fd.grad, 0, cut)
+        chunks = max(1, min(self.dp_chunks, nL))
+        done_blocks, hi = 0, fd.total
+        for c in range(chunks):
+            upto = (nL * (c + 1)) // chunks          # encoder blocks finished after this piece (counted from the top)
+            last = c == chunks - 1
+            s0 = 0 if c == 0 else 1 + done_blocks    # stage 0 = head + final LN, stages 1..L = blocks L-1..0, L+1 = embedding
+            s1 = nL + 2 if last else 1 + upto
+            _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, s0, s1, st), "vg_vit_backward_stages")
+            lo = 0 if last else lay.layer0 + (nL - upto) * lay.layer_stride  # blocks >= nL-upto and the head are final
+            self.sync.reduce_range(fd.grad, lo, hi)
+            done_blocks, hi = upto, lo
 
     def _adamw(self, fp, m, v, lr, st, clip=None, slot=0):
         h = self.hyp
