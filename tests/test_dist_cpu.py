@@ -84,3 +84,22 @@ def test_shard_batch():
     assert [shard_batch(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def test_backward_pieces_tile_the_gradient_buffer_exactly_once():
+    """Host logic of the overlapped D exchange: stage ranges are contiguous and increasing, gradient ranges tile
+    [0, total) from the top down, and a range is only released once every block in it has run."""
+    from vit_gan_amd.dist import backward_pieces
+    layer0, stride = 1000, 77
+    for L in (1, 2, 3, 6, 12):
+        total = layer0 + L * stride + 555  # embedding | L blocks | head
+        for chunks in (1, 2, 3, 4, 50):
+            plan = backward_pieces(L, chunks, layer0, stride, total)
+            assert plan[0][0] == 0 and plan[-1][1] == L + 2 and plan[0][3] == total and plan[-1][2] == 0
+            for (a0, a1, lo, hi), nxt in zip(plan, plan[1:] + [None]):
+                assert a0 < a1 and lo < hi
+                if nxt is not None:
+                    assert nxt[0] == a1 and nxt[3] == lo
+                    blocks_done = a1 - 1                      # stages 1..a1-1 = blocks L-1 .. L-blocks_done
+                    assert lo == layer0 + (L - blocks_done) * stride
+            assert len(plan) == max(1, min(chunks, L))

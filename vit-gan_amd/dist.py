@@ -27,6 +27,24 @@ def shard_batch(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def backward_pieces(n_layers: int, chunks: int, layer0: int, layer_stride: int, total: int):
+    """Plan of a staged ViT backward whose gradient exchange overlaps the remaining backward: a list of
+    ``(stage_begin, stage_end, lo, hi)`` - run stages [begin, end) of ``vg_vit_backward_stages`` (stage 0 = head + final
+    LayerNorm, stages 1..L = encoder blocks L-1..0, stage L+1 = patch embedding), after which the flat gradient range
+    [lo, hi) is final and can be all-reduced.  The ranges tile [0, total) from the top down, exactly once."""
+    chunks = max(1, min(int(chunks), n_layers))
+    out, done_blocks, hi = [], 0, total
+    for c in range(chunks):
+        upto = (n_layers * (c + 1)) // chunks  # encoder blocks finished after this piece, counted from the top
+        last = c == chunks - 1
+        s0 = 0 if c == 0 else 1 + done_blocks
+        s1 = n_layers + 2 if last else 1 + upto
+        lo = 0 if last else layer0 + (n_layers - upto) * layer_stride
+        out.append((s0, s1, lo, hi))
+        done_blocks, hi = upto, lo
+    return out
+
+
 class GradSync:
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
                  overlap: bool = True):

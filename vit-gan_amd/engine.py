@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, flat
-from .dist import GradSync
+from .dist import GradSync, backward_pieces
 from .generator import SirenGenerator
 from .modules import ViTDiscriminator, VisionTransformer
 
@@ -121,17 +121,9 @@ class GanEngine:
             return
         fd = self.vit._flat
         lay = flat.vit_layout(self.vit._dims)
-        chunks = max(1, min(self.dp_chunks, nL))
-        done_blocks, hi = 0, fd.total
-        for c in range(chunks):
-            upto = (nL * (c + 1)) // chunks          # encoder blocks finished after this piece (counted from the top)
-            last = c == chunks - 1
-            s0 = 0 if c == 0 else 1 + done_blocks    # stage 0 = head + final LN, stages 1..L = blocks L-1..0, L+1 = embedding
-            s1 = nL + 2 if last else 1 + upto
+        for s0, s1, lo, hi in backward_pieces(nL, self.dp_chunks, lay.layer0, lay.layer_stride, fd.total):
             _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, s0, s1, st), "vg_vit_backward_stages")
-            lo = 0 if last else lay.layer0 + (nL - upto) * lay.layer_stride  # blocks >= nL-upto and the head are final
             self.sync.reduce_range(fd.grad, lo, hi)
-            done_blocks, hi = upto, lo
 
     def _adamw(self, fp, m, v, lr, st, clip=None, slot=0):
         h = self.hyp
