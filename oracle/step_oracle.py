@@ -79,13 +79,15 @@ class GanStepOracle:
     def G(self, z: Tensor) -> Tensor:
         return gen_forward(self.g, z, self.gdims)
 
-    def step(self, real: Tensor, z: Tensor) -> Dict[str, float]:
+    def step(self, real: Tensor, z: Tensor, noisy_inputs=None) -> Dict[str, float]:
+        """noisy_inputs: optional (noisy_real, noisy_fake) the discriminator sees in ITS step (training.py:83-90:
+        real / fake + 0.1 randn); the generator's pass through D always uses the clean fake."""
         for p in self.d.values():
             p.grad = None
-        loss_real = d_loss_real(self.D(real), self.loss)
+        loss_real = d_loss_real(self.D(real if noisy_inputs is None else noisy_inputs[0]), self.loss)
         loss_real.backward()
         fake = self.G(z)
-        loss_fake = d_loss_fake(self.D(fake.detach()), self.loss)
+        loss_fake = d_loss_fake(self.D(fake.detach() if noisy_inputs is None else noisy_inputs[1]), self.loss)
         loss_fake.backward()
         if self.clip_d is not None:
             torch.nn.utils.clip_grad_norm_(list(self.d.values()), max_norm=self.clip_d)

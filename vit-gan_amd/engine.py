@@ -39,12 +39,14 @@ class GanEngine:
                  eps: float = 1e-8, fuse_real_fake: bool = True, use_graph: bool = False,
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
-                 diversity_weight: float = 0.0,
+                 diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
         Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
         diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
-        over this rank's batch - under data parallelism it is NOT the global-batch quantity)."""
+        over this rank's batch - under data parallelism it is NOT the global-batch quantity).
+        instance_noise: sigma of the Gaussian noise added to the discriminator's real and fake inputs in its own step
+        (0.1 there, training.py:83-90); the generator's pass through D sees the clean fake."""
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
             raise TypeError("GanEngine needs a ViTDiscriminator/VisionTransformer and a SirenGenerator")
@@ -64,6 +66,7 @@ class GanEngine:
         self.clip_d, self.clip_g = clip_d, clip_g
         self.dp_chunks = 3  # pieces of the D backward whose gradient exchange overlaps the remaining backward
         self.div_w = float(diversity_weight)
+        self.inst_sigma = float(instance_noise)
         self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
@@ -80,6 +83,9 @@ class GanEngine:
         self.ws_g = torch.empty(L.vg_gen_ws_bytes(C.byref(g), B), dtype=torch.uint8, device=dev)
         self.imgs = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)  # [real ; fake]
         self.dfake = torch.empty(B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)
+        if self.inst_sigma > 0.0:  # noisy copy of [real ; fake] for the D step, and the noise itself (kept for inspection / tests)
+            self.inoise = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.float32, device=dev)
+            self.imgs_noisy = torch.empty_like(self.imgs)
         self.div_scratch = torch.zeros((d.C * d.IH * d.IH + 15) // 16, dtype=torch.float32, device=dev)
         self.logits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
         self.dlogits = torch.empty(2 * B, d.Kc, dtype=torch.float32, device=dev)
@@ -152,14 +158,20 @@ class GanEngine:
         self.z.normal_()           # construct_noise(), training.py:35-42 / gan.py:231-232
         fd.grad.zero_()            # gan.discriminator.zero_grad(), training.py:177
         _lib.check(L.vg_gen_forward(C.byref(ng), B, _p(self.z), _p(self.ws_g), fake_ptr, st), "vg_gen_forward")
+        d_in = self.imgs
+        if self.inst_sigma > 0.0:  # noisy_real / noisy_fake of training.py:83-90 (the clean fake stays in self.imgs for pass C)
+            self.inoise.normal_()
+            torch.add(self.imgs.float(), self.inoise, alpha=self.inst_sigma, out=self.inoise)
+            self.imgs_noisy.copy_(self.inoise)
+            d_in = self.imgs_noisy
         if self.fuse:
-            _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(self.imgs), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
+            _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(d_in), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
             self._loss(0, B, 0, 0, st)
             self._loss(B, B, 1, 1, st)
             self._d_backward(nd, 2 * B, _p(self.dlogits), 1, None, st)
         else:
             for half, role in ((0, 0), (1, 1)):
-                src = C.c_void_p(self.imgs.data_ptr() + half * B * img_bytes)
+                src = C.c_void_p(d_in.data_ptr() + half * B * img_bytes)
                 lg = C.c_void_p(self.logits.data_ptr() + 4 * half * B * self.Kc)
                 dl = C.c_void_p(self.dlogits.data_ptr() + 4 * half * B * self.Kc)
                 net = nd if half == 0 else nd_b
