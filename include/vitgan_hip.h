@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 3
+#define VG_ABI_VERSION 4
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -48,9 +48,13 @@ int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* r
 int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode,
                     const void* Z, const float* Zf, float act_scale, void* stream);
 /* weight gradient of nn.Linear:  dW[N,K] (+)= dY[M,N]^T @ X[M,K], computed as `splits` slices of M
- * into fp32 slabs (slab_ws: splits*N*K floats) folded in a fixed order (deterministic). */
-int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, int M, int N, int K,
-                    int splits, int accumulate, void* stream);
+ * into fp32 slabs folded in a fixed order (deterministic).  slab_ws holds slab_floats floats and must be at
+ * least vg_linear_wgrad_slab_floats(N, K, splits) = splits*N*K: a smaller workspace, or splits outside
+ * [1, VG_WGRAD_MAX_SPLITS], returns -2 and launches nothing. */
+#define VG_WGRAD_MAX_SPLITS 64
+long long vg_linear_wgrad_slab_floats(int N, int K, int splits); /* host only; -2 for a bad argument */
+int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, long long slab_floats, int M,
+                    int N, int K, int splits, int accumulate, void* stream);
 
 /* nn.LayerNorm forward/backward (src/v2/modules.py:168,172,225; eps 1e-5, biased variance).
  * x,y bf16 [R,E] with row strides xs/ys (elements); mean/rstd fp32 [R]. E % 128 == 0, E <= 1024. */

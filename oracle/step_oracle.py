@@ -18,6 +18,7 @@ from typing import Callable, Dict, Mapping, Tuple
 import torch
 import torch.nn.functional as F
 
+from . import bf16_model
 from .gen_oracle import GenDims, gen_forward
 from .vit_oracle import VitDims, vit_forward
 
@@ -64,8 +65,12 @@ class GanStepOracle:
 
     def __init__(self, d_state: Mapping[str, Tensor], g_state: Mapping[str, Tensor],
                  ddims: VitDims, gdims: GenDims, lr_d: float = 5e-4, lr_g: float = 5e-4,
-                 weight_decay: float = 1e-3, loss: str = "ns", clip_d: float = None, clip_g: float = None):
+                 weight_decay: float = 1e-3, loss: str = "ns", clip_d: float = None, clip_g: float = None,
+                 faithful: bool = False):
+        """faithful: run both networks through ``bf16_model`` (bf16 roundings exactly where the HIP engine stores bf16,
+        fp32 master weights and optimizer) instead of the pure-fp32 restatement - the tight parity tier."""
         self.ddims, self.gdims, self.loss = ddims, gdims, loss
+        self.faithful = bool(faithful)
         self.clip_d, self.clip_g = clip_d, clip_g  # utils.clip_grad_norm_ max norms (training.py:78,104), None = off
         self.diversity_weight = 0.0                # weight of diversity_loss(fake) in the G loss (0.1 at training.py:73-74)
         self.d = {k: v.detach().clone().float().requires_grad_(True) for k, v in d_state.items()}
@@ -73,28 +78,35 @@ class GanStepOracle:
         self.opt_d = torch.optim.AdamW(list(self.d.values()), lr=lr_d, weight_decay=weight_decay)
         self.opt_g = torch.optim.AdamW(list(self.g.values()), lr=lr_g, weight_decay=weight_decay)
 
-    def D(self, x: Tensor) -> Tensor:
-        return vit_forward(self.d, x, self.ddims)
+    def D(self, x: Tensor, masks=None) -> Tensor:
+        if self.faithful:
+            return bf16_model.vit_forward(self.d, x, self.ddims, masks=masks)
+        return vit_forward(self.d, x, self.ddims, masks=masks)
 
-    def G(self, z: Tensor) -> Tensor:
-        return gen_forward(self.g, z, self.gdims)
+    def G(self, z: Tensor, masks=None) -> Tensor:
+        if self.faithful:
+            return bf16_model.gen_forward(self.g, z, self.gdims, masks=masks)
+        return gen_forward(self.g, z, self.gdims, masks=masks)
 
-    def step(self, real: Tensor, z: Tensor, noisy_inputs=None) -> Dict[str, float]:
+    def step(self, real: Tensor, z: Tensor, noisy_inputs=None, masks=None) -> Dict[str, float]:
         """noisy_inputs: optional (noisy_real, noisy_fake) the discriminator sees in ITS step (training.py:83-90:
-        real / fake + 0.1 randn); the generator's pass through D always uses the clean fake."""
+        real / fake + 0.1 randn); the generator's pass through D always uses the clean fake.
+        masks (test hook): explicit dropout multipliers standing in for nn.Dropout's RNG, a dict with the keys "d_real",
+        "d_fake", "d_gen" (the three discriminator passes) and "g", each a mask mapping of vit_forward / gen_forward."""
+        mk = masks or {}
         for p in self.d.values():
             p.grad = None
-        loss_real = d_loss_real(self.D(real if noisy_inputs is None else noisy_inputs[0]), self.loss)
+        loss_real = d_loss_real(self.D(real if noisy_inputs is None else noisy_inputs[0], mk.get("d_real")), self.loss)
         loss_real.backward()
-        fake = self.G(z)
-        loss_fake = d_loss_fake(self.D(fake.detach() if noisy_inputs is None else noisy_inputs[1]), self.loss)
+        fake = self.G(z, mk.get("g"))
+        loss_fake = d_loss_fake(self.D(fake.detach() if noisy_inputs is None else noisy_inputs[1], mk.get("d_fake")), self.loss)
         loss_fake.backward()
         if self.clip_d is not None:
             torch.nn.utils.clip_grad_norm_(list(self.d.values()), max_norm=self.clip_d)
         self.opt_d.step()
         for p in self.g.values():
             p.grad = None
-        loss_g = g_loss(self.D(fake), self.loss)
+        loss_g = g_loss(self.D(fake, mk.get("d_gen")), self.loss)
         total_g = loss_g + self.diversity_weight * diversity_loss(fake) if self.diversity_weight else loss_g
         total_g.backward()
         if self.clip_g is not None:

@@ -1,0 +1,83 @@
+"""The rounding-faithful model of the kernels' arithmetic (oracle/bf16_model.py) against the pinned fp32 oracle, on CPU.
+
+Two facts make it a legitimate second parity tier: with rounding switched off it IS the fp32 oracle (same outputs and
+gradients to fp32 reassociation), and with rounding on it stays inside the loose bf16 bounds the fp32 comparison uses.
+The GPU tests then hold the kernels to 2^-7 of max|ref| against it."""
+import numpy as np
+import pytest
+import torch
+
+from cases import GEN_CASES, VIT_CASES
+from weights import make_input, make_state
+
+from oracle import bf16_model as bm
+from oracle import gen_oracle as go
+from oracle import vit_oracle as vo
+
+
+def _grads(fn, st_np, inp, seed, needs_dx):
+    st = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st_np.items()}
+    x = inp.clone().requires_grad_(needs_dx)
+    out = fn(st, x)
+    R = torch.from_numpy(make_input(tuple(out.shape), seed)).to(torch.bfloat16).float()
+    (out * R).sum().backward()
+    return out.detach(), (x.grad if needs_dx else None), {k: p.grad for k, p in st.items()}
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("name", ["c1k10", "c5"])
+def test_vit_model_collapses_to_the_fp32_oracle_without_rounding(name, monkeypatch):
+    c = VIT_CASES[name]
+    d = vo.VitDims(channels=c["channels"], image=c["image"], patch=c["patch"], embed=c["embed"], heads=c["heads"],
+                   layers=c["layers"], mlp_ratio=c["mlp_ratio"], classes=c["classes"])
+    st_np = make_state(vo.vit_param_shapes(d), c["seed"], "vit")
+    x = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"], "uniform"))
+    ref = _grads(lambda s, i: vo.vit_forward(s, i, d), st_np, x, c["seed"] + 1, True)
+    monkeypatch.setattr(bm, "_ROUND", False)
+    got = _grads(lambda s, i: bm.vit_forward(s, i, d), st_np, x, c["seed"] + 1, True)
+    assert _rel(got[0], ref[0]) < 1e-5 and _rel(got[1], ref[1]) < 1e-4
+    for k in ref[2]:
+        if float(ref[2][k].abs().max()) > 1e-6:
+            assert _rel(got[2][k], ref[2][k]) < 2e-4, k
+    monkeypatch.setattr(bm, "_ROUND", True)
+    rnd = _grads(lambda s, i: bm.vit_forward(s, i, d), st_np, x, c["seed"] + 1, True)
+    assert 1e-5 < _rel(rnd[0], ref[0]) < 2.0 ** -5 and _rel(rnd[1], ref[1]) < 2.0 ** -4   # rounding is on, and bounded
+    for k in ref[2]:
+        if float(ref[2][k].abs().max()) > 1e-6:
+            assert _rel(rnd[2][k], ref[2][k]) < 2.0 ** -4, k
+
+
+def test_generator_model_collapses_to_the_fp32_oracle_without_rounding(monkeypatch):
+    c = GEN_CASES["g1"]
+    d = go.GenDims()
+    st_np = make_state(go.gen_param_shapes(d), c["seed"], "gen")
+    z = torch.from_numpy(make_input((c["batch"], d.latent), c["seed"]))
+    ref = _grads(lambda s, i: go.gen_forward(s, i, d), st_np, z, c["seed"] + 1, False)
+    monkeypatch.setattr(bm, "_ROUND", False)
+    got = _grads(lambda s, i: bm.gen_forward(s, i, d), st_np, z, c["seed"] + 1, False)
+    assert _rel(got[0], ref[0]) < 1e-4
+    for k in ref[2]:
+        assert _rel(got[2][k], ref[2][k]) < 1e-3, k
+    monkeypatch.setattr(bm, "_ROUND", True)
+    rnd = _grads(lambda s, i: bm.gen_forward(s, i, d), st_np, z, c["seed"] + 1, False)
+    assert 1e-4 < _rel(rnd[0], ref[0]) < 0.08
+    for k in ref[2]:
+        assert _rel(rnd[2][k], ref[2][k]) < (0.35 if k.endswith(("gamma", "beta")) else 0.12), k
+
+
+def test_faithful_step_oracle_tracks_the_fp32_step_oracle():
+    from oracle import step_oracle as so
+    dd, gd = vo.VitDims(layers=1, classes=1), go.GenDims(layers=1)
+    ds, gs = vo.init_vit_state(dd, 0), go.init_gen_state(gd, 1)
+    a = so.GanStepOracle(ds, gs, dd, gd)
+    b = so.GanStepOracle(ds, gs, dd, gd, faithful=True)
+    g = torch.Generator().manual_seed(3)
+    real = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+    z = torch.randn(4, gd.latent, generator=g)
+    ra, rb = a.step(real, z), b.step(real, z)
+    for k in ra:
+        assert abs(ra[k] - rb[k]) < 2e-2, (k, ra, rb)
+    assert any(ra[k] != rb[k] for k in ra)

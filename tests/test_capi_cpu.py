@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vitgan_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert set(_lib._SIGNATURES) <= set(names), set(_lib._SIGNATURES) - set(names)
-    assert lib.vg_abi_version() == 3
+    assert lib.vg_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
@@ -43,6 +43,47 @@ def test_argument_validation_without_gpu():
     assert lib.vg_vit_ws_bytes(C.byref(d), 4) == -1
     d = _lib.VgVitDims(3, 64, 4, 384, 4, 6, 2, 1)  # 257 tokens > 80
     assert lib.vg_vit_layout(C.byref(d), C.byref(_lib.VgVitLayout())) == -3
+
+
+def test_unsupported_depths_are_rejected_not_overflowed():
+    """the backward queues 3 folds per ViT block (2L+1 for the generator) into a 40-entry host array and uses
+    one event pair per block; depths beyond that used to write past the array.  The layouts now refuse them."""
+    lib = _lib.lib()
+    ok = _lib.VgVitDims(3, 32, 4, 128, 4, 13, 2, 1)
+    assert lib.vg_vit_layout(C.byref(ok), C.byref(_lib.VgVitLayout())) == 0
+    for L in (14, 20, 71, 500):
+        d = _lib.VgVitDims(3, 32, 4, 128, 4, L, 2, 1)
+        assert lib.vg_vit_layout(C.byref(d), C.byref(_lib.VgVitLayout())) == -3, L
+        assert lib.vg_vit_ws_bytes(C.byref(d), 2) == -1
+    g_ok = _lib.VgGenDims(128, 32, 128, 4, 19, 128, 96, 30.0, 0, 3, 32)
+    assert lib.vg_gen_layout(C.byref(g_ok), C.byref(_lib.VgGenLayout())) == 0
+    g_bad = _lib.VgGenDims(128, 32, 128, 4, 20, 128, 96, 30.0, 0, 3, 32)
+    assert lib.vg_gen_layout(C.byref(g_bad), C.byref(_lib.VgGenLayout())) == -3
+    with pytest.raises(_lib.HipError):
+        from vit_gan_amd.modules import ViTDiscriminator
+        ViTDiscriminator(Config(transformer_blocks_count=14))
+
+
+def test_wgrad_slab_validation_without_gpu():
+    """The split-K slab can no longer be overrun through the public entry point: size and split count are checked on the
+    host before anything is launched (round-1 fault: slices written past a slab carved for 8)."""
+    lib = _lib.lib()
+    assert lib.vg_linear_wgrad_slab_floats(384, 384, 8) == 8 * 384 * 384
+    assert lib.vg_linear_wgrad_slab_floats(384, 384, 65) == -2
+    fake = C.c_void_p(4096)  # never dereferenced: validation fails first
+    assert lib.vg_linear_wgrad(fake, fake, fake, fake, 8 * 384 * 384 - 1, 1024, 384, 384, 8, 0, None) == -2
+    assert lib.vg_linear_wgrad(fake, fake, fake, fake, 1 << 40, 1024, 384, 384, 65, 0, None) == -2
+    assert lib.vg_linear_wgrad(fake, fake, fake, None, 1 << 40, 1024, 384, 384, 2, 0, None) == -1
+
+
+def test_product_library_reads_no_environment():
+    """Tuning knobs (VG_VIT_SPLITS / VG_GEMM_T4MIN / VG_GEMM_WM) exist only in `make var` builds (-DVG_TUNING)."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"VG_VIT_SPLITS", b"VG_GEMM_T4MIN", b"VG_GEMM_WM", b"VG_STAMP_PTR"):
+        assert name not in blob, name
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in nm
 
 
 @pytest.mark.parametrize("dims", [(3, 32, 4, 384, 4, 6, 2, 1), (3, 32, 4, 128, 4, 6, 2, 10), (3, 64, 8, 512, 8, 6, 2, 1),
@@ -68,7 +109,9 @@ def lib_ws(d):
 
 def test_config_is_the_references():
     c = Config()
-    assert list(Config.model_fields) == ["attention_heads_count", "batch_size", "classes_count", "discriminator_learning_rate",
+    # the reference's 15 fields in its order, then the build's one extra field (hidden from repr / str)
+    assert list(Config.model_fields)[-1] == "generator_kind" and c.generator_kind == "v2"
+    assert list(Config.model_fields)[:15] == ["attention_heads_count", "batch_size", "classes_count", "discriminator_learning_rate",
                                          "dropout_rate", "embeddings_dimension", "epochs", "generator_learning_rate", "image_size",
                                          "input_channels", "mlp_ratio", "optimizer_beta1", "optimizer_beta2", "patch_size",
                                          "transformer_blocks_count"]

@@ -49,11 +49,16 @@ def test_vit_train_mode_matches_oracle_with_same_masks():
     for l in range(d.layers):
         masks[("attn", l)] = _mask(u, (B, S, E), p, seed, 1 + 2 * l)
         masks[("mlp", l)] = _mask(u, (B, S, E), p, seed, 2 + 2 * l)
+    from oracle import bf16_model as bm
     st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
     xr = x.clone().requires_grad_(True)
     out = vo.vit_forward(st, xr, d, masks=masks)
     R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
     (out * R).sum().backward()
+    st_t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    xt = x.clone().requires_grad_(True)
+    out_t = bm.vit_forward(st_t, xt, d, masks=masks)   # tight tier: the rounding-faithful model with the same masks
+    (out_t * R).sum().backward()
     out_eval = vo.vit_forward(st, x, d).detach()
     assert float((out.detach() - out_eval).abs().max()) > 1e-2  # dropout really changes the result
 
@@ -70,12 +75,15 @@ def test_vit_train_mode_matches_oracle_with_same_masks():
     u.call("vg_vit_backward", C.byref(net), B, u.ptr(ws), u.ptr(Rd), u.ptr(dimg), 1, u.stream())
     u.sync()
     # 13 dropout sites scale surviving activations by 256/230: bf16 rounding noise grows accordingly (2^-4 here, 2^-5 in eval)
+    u.assert_close(logits, out_t, 2.0 ** -7, "logits (train mode, tight)")
+    u.assert_close(dimg, xt.grad, 2.0 ** -7, "d_img (train mode, tight)")
     u.assert_close(logits, out, 2.0 ** -4, "logits (train mode)")
     u.assert_close(dimg, xr.grad, 2.0 ** -4, "d_img (train mode)")
     grads = flat.unpack(slots, G)
     for k, prm in st.items():
         if float(prm.grad.abs().max()) < 1e-6:
             continue
+        u.assert_close(grads[k], st_t[k].grad, 2.0 ** -7, f"grad {k} (train mode, tight)")
         u.assert_close(grads[k], prm.grad, 2.0 ** -4, f"grad {k} (train mode)")
     # staged backward == one-shot backward, bit for bit
     G2 = torch.zeros_like(P)
@@ -101,10 +109,14 @@ def test_generator_train_mode_matches_oracle_with_same_masks():
     for l in range(d.layers):
         masks[("attn", l)] = _mask(u, (B, d.tokens, d.embed), p, seed, 100 + 2 * l)
         masks[("mlp", l)] = _mask(u, (B, d.tokens, d.embed), p, seed, 101 + 2 * l)
+    from oracle import bf16_model as bm
     st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
     out = go.gen_forward(st, z, d, masks=masks)
-    R = torch.from_numpy(make_input(tuple(out.shape), 22))
+    R = torch.from_numpy(make_input(tuple(out.shape), 22)).to(torch.bfloat16).float()
     (out * R).sum().backward()
+    st_t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    out_t = bm.gen_forward(st_t, z, d, masks=masks)
+    (out_t * R).sum().backward()
     gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0)
     lay, slots = flat.gen_layout(gd), flat.gen_slots(gd)
     P = flat.pack(slots, lay.total, st_np, device="cuda")
@@ -116,9 +128,11 @@ def test_generator_train_mode_matches_oracle_with_same_masks():
     u.call("vg_gen_forward", C.byref(net), B, u.ptr(Zd), u.ptr(ws), u.ptr(img), u.stream())
     u.call("vg_gen_backward", C.byref(net), B, u.ptr(ws), u.ptr(Rd), u.stream())
     u.sync()
+    u.assert_close(img, out_t, 2.0 ** -7, "generated image (train mode, tight)")
     u.assert_close(img, out, 0.08, "generated image (train mode)")
     grads = flat.unpack(slots, G)
     for k, prm in st.items():
+        u.assert_close(grads[k], st_t[k].grad, 2.0 ** -7, f"grad {k} (train mode, tight)", floor=1e-6)
         tol = 0.35 if k.endswith(("gamma", "beta")) else 0.12
         u.assert_close(grads[k], prm.grad, tol, f"grad {k} (train mode)", floor=1e-4)
 

@@ -126,22 +126,144 @@ def test_dropout_path_and_state_dict_roundtrip():
     assert float((yc - y0).abs().max()) < 2.0 ** -5 * float(y0.abs().max()) + 1e-3
 
 
-def test_engine_graph_replay_equals_eager():
+def _bench_like(B, seed=5, d_layers=2, g_layers=2, **kw):
+    """The configuration bench.py measures - train-mode dropout (D 0.1 / G 0.2), fused real+fake pass, two-stream
+    weight gradients - at a size the CPU model finishes in seconds; the noise comes from the caller (external_noise)."""
+    import vit_gan_amd  # noqa: F401
+    from vit_gan_amd.config import Config
     from vit_gan_amd.engine import GanEngine
-    B = 4
-    outs = []
-    for use_graph in (False, True):
-        D, G, _ = _build(B, seed=5)
-        eng = GanEngine(D, G, batch=B, use_graph=use_graph)
-        torch.manual_seed(11)
-        real = (torch.rand(B, 3, 32, 32, generator=torch.Generator().manual_seed(4)) * 2 - 1).cuda()
-        for _ in range(3):
-            l = eng.step(real)
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator
+    torch.manual_seed(seed)
+    cfg = Config(embeddings_dimension=384, classes_count=1, dropout_rate=0.1, batch_size=B, transformer_blocks_count=d_layers)
+    D = ViTDiscriminator(cfg).train()
+    G = SirenGenerator(layers=g_layers, dropout=0.2).train()
+    state = ({k: v.detach().clone() for k, v in D.state_dict().items()}, {k: v.detach().clone() for k, v in G.state_dict().items()})
+    opts = dict(batch=B, seed=77, external_noise=True, fuse_real_fake=True, concurrent_wgrad=True)
+    opts.update(kw)
+    eng = GanEngine(D.cuda(), G.cuda(), **opts)
+    return eng, D, G, state
+
+
+def _run_steps(eng, n, B, data_seed=4):
+    g = torch.Generator().manual_seed(data_seed)
+    losses = []
+    for _ in range(n):
+        real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+        z = torch.randn(B, 1024, generator=g).cuda()
+        losses.append(eng.step(real, z).clone())
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu(), [t.detach().clone().cpu() for t in eng._state_tensors()]
+
+
+def test_engine_graph_replay_equals_eager():
+    """hipGraph replay (what bench.py times at N=1) against the eager enqueue of the same steps: every piece of training
+    state - both master weight buffers, both bf16 shadows, all four AdamW moment buffers, the step counter - and the
+    losses of all three steps must be BIT-equal (the kernels are deterministic; N calls of step() are N steps in both
+    modes).  The single-stream eager schedule must give the same bits as the two-stream one."""
+    B, n = 4, 3
+    runs = {}
+    for name, kw in (("eager", dict(use_graph=False)), ("graph", dict(use_graph=True)),
+                     ("eager_1stream", dict(use_graph=False, concurrent_wgrad=False))):
+        eng, D, G, _ = _bench_like(B, **kw)
+        assert eng.p_d == 0.1 and eng.p_g == 0.2 and eng.fuse
+        runs[name] = _run_steps(eng, n, B)
+        assert eng.steps == n and int(eng.step_t) == n, (name, eng.steps, int(eng.step_t))
+    ref_l, ref_s = runs["eager"]
+    assert torch.isfinite(ref_l).all() and float(ref_s[0].abs().sum()) > 0
+    for name in ("graph", "eager_1stream"):
+        l, s = runs[name]
+        assert torch.equal(l, ref_l), (name, l, ref_l)
+        for i, (a, b) in enumerate(zip(s, ref_s)):
+            assert torch.equal(a, b), f"{name}: state tensor {i} differs from the eager run"
+
+
+def _step_masks(u, eng, B, step):
+    """The dropout multipliers the engine's step `step` (1-based device counter) applies, extracted through
+    vg_dropout_apply with the same (seed, site, step) key material: pass A = fused [real ; fake], C = G's pass through
+    D, and the generator's own sites."""
+    d, g = eng.vit._dims, eng.gen._dims
+    S = (d.IH // d.P) ** 2 + 1
+    st = torch.tensor([step], dtype=torch.int32, device="cuda")
+
+    def mask(shape, p, seed, site):
+        ones = torch.ones(shape, dtype=torch.bfloat16, device="cuda")
+        out = torch.empty_like(ones)
+        u.call("vg_dropout_apply", u.ptr(ones), u.ptr(out), ones.numel(), p, seed, site, u.ptr(st), u.stream())
+        u.sync()
+        return out.float().cpu()
+
+    def vit_masks(n_img, seed):
+        m = {"embed": mask((n_img, S, d.E), eng.p_d, seed, 0)}
+        for l in range(d.L):
+            m[("attn", l)] = mask((n_img, S, d.E), eng.p_d, seed, 1 + 2 * l)
+            m[("mlp", l)] = mask((n_img, S, d.E), eng.p_d, seed, 2 + 2 * l)
+        return m
+    a = vit_masks(2 * B, eng.seed * 8 + 0)
+    gm = {}
+    for l in range(g.L):
+        gm[("attn", l)] = mask((B, g.T, g.E), eng.p_g, eng.seed * 8 + 7, 100 + 2 * l)
+        gm[("mlp", l)] = mask((B, g.T, g.E), eng.p_g, eng.seed * 8 + 7, 101 + 2 * l)
+    return {"d_real": {k: v[:B] for k, v in a.items()}, "d_fake": {k: v[B:] for k, v in a.items()},
+            "d_gen": vit_masks(B, eng.seed * 8 + 2), "g": gm}
+
+
+def test_benchmarked_configuration_matches_the_step_model():
+    """The step bench.py measures - hipGraph replay + fused real/fake pass + two-stream weight gradients + train-mode
+    dropout - against the rounding-faithful step model (oracle.step_oracle, faithful=True) fed the SAME noise and the
+    SAME dropout masks: losses of two consecutive steps and the weights after them."""
+    import gpu_util as u
+    from oracle import gen_oracle as go, step_oracle as so, vit_oracle as vo
+    B = 8
+    eng, D, G, (d_state, g_state) = _bench_like(B, use_graph=True)
+    model = so.GanStepOracle(d_state, g_state, vo.VitDims(layers=2, classes=1), go.GenDims(layers=2), faithful=True)
+    loose = so.GanStepOracle(d_state, g_state, vo.VitDims(layers=2, classes=1), go.GenDims(layers=2))
+    g = torch.Generator().manual_seed(9)
+    w0 = {k: v.clone() for k, v in d_state.items()}
+    for it in range(2):
+        real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+        z = torch.randn(B, 1024, generator=g)
+        got = eng.step(real.cuda(), z.cuda()).cpu().tolist()
         torch.cuda.synchronize()
-        assert torch.isfinite(l).all()
-        outs.append((eng.steps, float(D.vit._flat.flat.abs().sum())))
-    # graph mode runs warm-up + capture (2 extra enqueues) so weights differ; both must be finite and trained
-    assert all(np.isfinite(o[1]) for o in outs)
+        masks = _step_masks(u, eng, B, it + 1)
+        ref = model.step(real, z, masks=masks)
+        ref32 = loose.step(real, z, masks=masks)
+        print(f"step {it}: engine {[round(x, 5) for x in got]} model {ref} fp32 {ref32}")
+        for x, k in zip(got, ("d_real", "d_fake", "g")):
+            assert abs(x - ref[k]) < (3e-3 if it == 0 else 6e-3), (it, k, got, ref)   # tight tier
+            assert abs(x - ref32[k]) < (2e-2 if it == 0 else 4e-2), (it, k, got, ref32)  # loose tier
+    # after two AdamW steps: each weight moved by ~lr per step in the direction of its gradient's sign, so the engine and
+    # the model agree except where a gradient is at rounding-noise level (a flipped sign costs 2 lr per step)
+    sd = {k: v.detach().cpu() for k, v in D.state_dict().items()}
+    for k in ("vit.encoder.1.fc2.weight", "vit.encoder.0.attention.values.weight", "vit.classifier.fc1.weight", "vit.embedding.conv1.weight"):
+        ref_w = model.d[k].detach()
+        diff = (sd[k] - ref_w).abs()
+        moved = float((ref_w - w0[k]).abs().mean())
+        assert moved > 2e-4, (k, moved)
+        assert float(diff.max()) < 2.1e-3, k
+        agree = float((diff < 5e-5).float().mean())
+        print(f"{k}: {agree:.4f} of the weights within 5e-5 of the model after 2 steps (mean |update| {moved:.2e})")
+        assert agree > 0.97, (k, agree)
+
+
+def test_load_state_dict_after_engine_construction_refreshes_the_shadows():
+    """load_state_dict copies into the flat master buffers in place; without a refresh the next step's
+    discriminator / generator passes would read the stale bf16 shadows.  One step after a late load must equal, bit for
+    bit, the step of an engine built after the load."""
+    from vit_gan_amd.modules import ViTGAN
+    B = 4
+    eng_a, D_a, G_a, _ = _bench_like(B, seed=5, use_graph=False)
+    eng_b, D_b, G_b, (d_other, g_other) = _bench_like(B, seed=6, use_graph=False)   # different weights
+    assert not torch.equal(D_a.vit._flat.flat, D_b.vit._flat.flat)
+    D_a.load_state_dict(d_other, strict=True)       # late load: engine A existed already
+    G_a.load_state_dict(g_other, strict=True)
+    la, sa = _run_steps(eng_a, 1, B)
+    lb, sb = _run_steps(eng_b, 1, B)
+    assert torch.equal(la, lb)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert torch.equal(a, b), f"state tensor {i}"
+    eng_a.sync_from_modules(reset_optimizer=True)
+    assert int(eng_a.step_t) == 0 and float(eng_a.m_d.abs().sum()) == 0.0
 
 
 def _dp_worker(rank, world, port, out):

@@ -1,9 +1,14 @@
 """Whole-network parity through the C ABI: vg_vit_forward/backward and vg_gen_forward/backward
 against the fp32 CPU oracle on the golden-fixture parameters.
 
-bf16 compute vs fp32 oracle: tolerance atol = 2^-5 * max|ref| per tensor for multi-layer
-outputs/gradients (2^-7 per rounding, accumulated over a 6-block trunk); stated per assertion.
+Two tolerance tiers, both per tensor as a fraction of max|ref|:
+  TIGHT = 2^-7 against oracle/bf16_model.py, the CPU model that rounds to bf16 exactly where the kernels store bf16 -
+          what is left is fp32 summation order and a sparse set of one-ulp rounding flips, so a mis-scaled gradient or a
+          wrong residual cannot hide (SURVEY 8d's bf16 bound);
+  LOOSE = the distance between bf16 storage and the reference's fp32 arithmetic itself, against the fp32 oracle that
+          is pinned to the reference: 2^-5 logits / 2^-4 gradients for the ViT, 0.08 / 0.12 / 0.35 behind sin(30 x).
 """
+TIGHT = 2.0 ** -7
 import ctypes as C
 
 import numpy as np
@@ -37,13 +42,17 @@ def test_vit_forward_backward_vs_oracle(name, batch):
     from vit_gan_amd import _lib, flat
     from weights import make_input
 
+    from oracle import bf16_model as bm
     B = c["batch"]
-    # oracle (fp32, CPU) on bf16-rounded weights for the GEMM operands is NOT used: compare against the true fp32 oracle
     st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
     xr = x.clone().requires_grad_(True)
-    out = vo.vit_forward(st, xr, d)
+    out = vo.vit_forward(st, xr, d)                      # LOOSE tier: the fp32 oracle pinned to the reference
     R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
     (out * R).sum().backward()
+    st_t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    xt = x.clone().requires_grad_(True)
+    out_t = bm.vit_forward(st_t, xt, d)                  # TIGHT tier: bf16 roundings where the kernels round
+    (out_t * R).sum().backward()
 
     dd = flat.vit_dims_struct(d.channels, d.image, d.patch, d.embed, d.heads, d.layers, d.mlp_ratio, d.classes)
     lay = flat.vit_layout(dd)
@@ -57,23 +66,29 @@ def test_vit_forward_backward_vs_oracle(name, batch):
     X = x.cuda()
     u.call("vg_vit_forward", C.byref(net), B, u.ptr(X), 0, u.ptr(ws), u.ptr(logits), u.stream())
     u.sync()
+    u.assert_close(logits, out_t, TIGHT, "logits (tight)")
     u.assert_close(logits, out, 2.0 ** -5, "logits")
     dimg = torch.empty(B, d.channels, d.image, d.image, dtype=torch.bfloat16, device="cuda")
     Rd = R.cuda()
     u.call("vg_vit_backward", C.byref(net), B, u.ptr(ws), u.ptr(Rd), u.ptr(dimg), 1, u.stream())
     u.sync()
+    u.assert_close(dimg, xt.grad, TIGHT, "d_img (tight)")
     u.assert_close(dimg, xr.grad, 2.0 ** -4, "d_img")
     grads = {k: v.clone() for k, v in flat.unpack(slots, G).items()}
     worst = 0.0
     for k, p in st.items():
         ref = p.grad
         if float(ref.abs().max()) < 1e-6:
-            # keys.bias: softmax is invariant to a key shift, the true gradient is 0; ours is bf16
-            # rounding noise summed over B*S rows - bound it by the sibling queries.bias gradient
-            sib = st[k.replace("keys", "queries")].grad
-            assert float(grads[k].abs().max()) < 2.0 ** -4 * float(sib.abs().max()) + 1e-4, k
+            # keys.bias: softmax is invariant to a key shift, the true gradient is 0; ours is bf16 rounding noise summed
+            # over B*S rows - and the rounding-faithful model reproduces that noise: compare with IT, relative to the
+            # sibling queries.bias gradient
+            sib = float(st[k.replace("keys", "queries")].grad.abs().max())
+            assert float((grads[k].cpu() - st_t[k].grad).abs().max()) < TIGHT * sib + 1e-6, k
+            assert float(grads[k].abs().max()) < 2.0 ** -4 * sib + 1e-4, k
             continue
-        worst = max(worst, u.assert_close(grads[k], ref, 2.0 ** -4, f"grad {k}"))
+        worst = max(worst, u.assert_close(grads[k], st_t[k].grad, TIGHT, f"grad {k} (tight)"))
+        u.assert_close(grads[k], ref, 2.0 ** -4, f"grad {k}")
+    print(f"{name}: worst tight-tier gradient error {worst:.2e} of max|ref| (bound {TIGHT:.2e})")
     # accumulate semantics: a second backward doubles G
     u.call("vg_vit_backward", C.byref(net), B, u.ptr(ws), u.ptr(Rd), None, 1, u.stream())
     u.sync()
@@ -97,26 +112,32 @@ def test_gen_forward_backward_vs_oracle(name):
     st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
     z = torch.from_numpy(make_input((B, d.latent), c["seed"]))
     out = go.gen_forward(st, z, d)
-    R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1))
+    R = torch.from_numpy(make_input(tuple(out.shape), c["seed"] + 1)).to(torch.bfloat16).float()  # d_img is handed over in bf16
     (out * R).sum().backward()
 
     gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0, 0, d.channels, d.image)
     _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B)
 
 
-def _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B):
+def _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B, pos_table=None):
+    from oracle import bf16_model as bm
     from vit_gan_amd import _lib, flat
+    st_t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    out_t = bm.gen_forward(st_t, z, d, pos_table=pos_table)   # TIGHT tier
+    (out_t * R).sum().backward()
     lay = flat.gen_layout(gd)
     slots = flat.gen_slots(gd)
     P = flat.pack(slots, lay.total, st_np, device="cuda")
     Pb = P.to(torch.bfloat16)
     G = torch.zeros_like(P)
-    net = _lib.VgGenNet(gd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), 0.0, 0, None)
+    tab = None if pos_table is None else pos_table.cuda().contiguous()
+    net = _lib.VgGenNet(gd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), 0.0, 0, None, None if tab is None else tab.data_ptr())
     ws = torch.empty(_lib.lib().vg_gen_ws_bytes(C.byref(gd), B), dtype=torch.uint8, device="cuda")
     img = torch.empty(B, d.channels, d.image, d.image, dtype=torch.bfloat16, device="cuda")
     Zd = z.cuda()
     u.call("vg_gen_forward", C.byref(net), B, u.ptr(Zd), u.ptr(ws), u.ptr(img), u.stream())
     u.sync()
+    u.assert_close(img, out_t, TIGHT, "generated image (tight)")
     # sin(30 * z): a bf16 rounding of the 768-wide hidden layer moves the phase; images live in [-1, 1]
     u.assert_close(img, out, 0.08, "generated image")
     Rd = R.to(torch.bfloat16).cuda()
@@ -125,11 +146,13 @@ def _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, B):
     grads = flat.unpack(slots, G)
     rel = {}
     for k, p in st.items():
-        # sin(30 z) amplifies each bf16 rounding of its input ~30x; SLN scalars (gamma, beta) are
-        # heavily cancelling sums over B*T*E products: 0.35, everything else 0.12 of max|ref|
+        # TIGHT tier first - every tensor, the SLN scalars (gamma, beta) included, at 2^-7 of max|ref|
+        rel[k] = u.assert_close(grads[k], st_t[k].grad, TIGHT, f"grad {k} (tight)", floor=1e-6)
+        # LOOSE tier: sin(30 z) amplifies each bf16 rounding of its input ~30x; the SLN scalars are heavily cancelling
+        # sums over B*T*E products: 0.35, everything else 0.12 of max|ref| - the price of bf16 storage, not of the kernels
         tol = 0.35 if k.endswith(("gamma", "beta")) else 0.12
-        rel[k] = u.assert_close(grads[k], p.grad, tol, f"grad {k}", floor=1e-4)
-    print("worst relative grad errors:", sorted(rel.items(), key=lambda kv: -kv[1])[:5])
+        u.assert_close(grads[k], p.grad, tol, f"grad {k}", floor=1e-4)
+    print("worst tight-tier grad errors:", [(k, f"{v:.2e}") for k, v in sorted(rel.items(), key=lambda kv: -kv[1])[:5]])
 
 
 @pytest.mark.parametrize("image,patch,embed,heads,batch", [(32, 4, 384, 4, 3), (64, 8, 512, 8, 2), (128, 16, 256, 4, 1)])
@@ -149,7 +172,7 @@ def test_patch_grid_generator_vs_oracle(image, patch, embed, heads, batch):
     z = torch.from_numpy(make_input((batch, d.latent), 5))
     out = go.gen_forward(st, z, d)
     assert out.shape == (batch, 3, image, image)
-    R = torch.from_numpy(make_input(tuple(out.shape), 6))
+    R = torch.from_numpy(make_input(tuple(out.shape), 6)).to(torch.bfloat16).float()
     (out * R).sum().backward()
     gd = _lib.VgGenDims(d.latent, d.tokens, d.embed, d.heads, d.layers, d.siren_hidden, d.out_features, d.omega0, patch, 3, image)
     _run_gen_vs_oracle(u, gd, d, st, st_np, z, out, R, batch)
@@ -191,14 +214,69 @@ def test_generator_with_fourier_position_input(patch):
     st = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
     G = G.cuda()
     z = torch.from_numpy(make_input((3, 128), 8))
+    from oracle import bf16_model as bm
     ref = go.gen_forward(st, z, d, pos_table=tab)
-    R = torch.from_numpy(make_input(tuple(ref.shape), 9))
+    R = torch.from_numpy(make_input(tuple(ref.shape), 9)).to(torch.bfloat16).float()
     (ref * R).sum().backward()
+    st_t = {k: v.detach().clone().requires_grad_(True) for k, v in st.items()}
+    ref_t = bm.gen_forward(st_t, z, d, pos_table=tab)
+    (ref_t * R).sum().backward()
     out = G(z.cuda())
+    u.assert_close(out, ref_t, TIGHT, "image (tight)")
     u.assert_close(out, ref, 0.08, "image")
     no_table = go.gen_forward({k: v.detach() for k, v in st.items()}, z, d)
     assert float((ref.detach() - no_table).abs().max()) > 0.1  # the table matters
     (out * R.cuda()).sum().backward()
     got = dict(G.named_parameters())
     for k in ("output_network.0.linear.weight", "transformer_layers.0.mlp.model.0.0.weight", "embedding", "mapping_mlp.model.0.0.bias"):
+        u.assert_close(got[k].grad, st_t[k].grad, TIGHT, f"grad {k} (tight)", floor=1e-6)
         u.assert_close(got[k].grad, st[k].grad, 0.12, f"grad {k}", floor=1e-4)
+
+
+def test_v2_vitgenerator_on_hip_matches_reference_fixture():
+    """the product's ``ViTGenerator`` (src/v2/modules.py:344-372) run on the HIP path against the
+    reference's own outputs (tests/golden/vitgen_v2.npz, generated by importing the reference): the trunk output, the
+    Linear(K, batch_size) + flat view where it is legal (batch_size^2 % 3072 == 0), and the reference's exact exception
+    text where it is not."""
+    import os
+    import gpu_util as u
+    from cases import VIT_CASES
+    from weights import make_input, make_state, summarize
+    from oracle import bf16_model as bm, vit_oracle as vo
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.modules import ViTGenerator
+
+    c = VIT_CASES["c1k10"]
+    npz = np.load(os.path.join(os.path.dirname(__file__), "golden", "vitgen_v2.npz"))
+    d = vo.VitDims(channels=c["channels"], image=c["image"], patch=c["patch"], embed=c["embed"], heads=c["heads"],
+                   layers=c["layers"], mlp_ratio=c["mlp_ratio"], classes=c["classes"])
+    for bs, tag in ((c["batch"], "illegal"), (96, "legal")):
+        cfg = Config(attention_heads_count=c["heads"], batch_size=bs, classes_count=c["classes"], dropout_rate=0.0,
+                     embeddings_dimension=c["embed"], image_size=c["image"], input_channels=c["channels"],
+                     mlp_ratio=c["mlp_ratio"], patch_size=c["patch"], transformer_blocks_count=c["layers"])
+        G = ViTGenerator(cfg)
+        assert list(G.state_dict().keys()) == [str(s) for s in npz[f"{tag}/state_keys"]]
+        st = {k: torch.from_numpy(v) for k, v in make_state(vo.vit_param_shapes(d), c["seed"], "vit").items()}
+        rng = np.random.Generator(np.random.PCG64(99))
+        st["linear.weight"] = torch.from_numpy((rng.standard_normal(size=(bs, c["classes"])) * 0.3).astype(np.float32))
+        st["linear.bias"] = torch.from_numpy((rng.standard_normal(size=(bs,)) * 0.1).astype(np.float32))
+        G.load_state_dict(st, strict=True)
+        G = G.cuda().eval()
+        x = torch.from_numpy(make_input((bs, c["channels"], c["image"], c["image"]), c["seed"]))
+        with torch.no_grad():
+            trunk = G.vit(x.cuda())
+            u.assert_close(trunk, bm.vit_forward(st, x, d), TIGHT, f"{tag}: vit(x) (tight)")
+            u.assert_close(trunk, torch.from_numpy(npz[f"{tag}/vit_out"]), 2.0 ** -5, f"{tag}: vit(x) vs the reference's output")
+            err = str(npz[f"{tag}/error"])
+            if err:
+                with pytest.raises(RuntimeError) as ei:
+                    G(x.cuda())
+                assert f"RuntimeError: {ei.value}" == err
+            else:
+                y = G(x.cuda())
+                assert list(y.shape) == list(npz[f"{tag}/out_shape"])   # batch_size^2 / 3072 images, not batch_size
+                s = summarize(y.float().cpu().numpy())
+                ref_norm = float(npz[f"{tag}/out/norm"])
+                assert abs(float(s["norm"]) - ref_norm) < 2.0 ** -6 * ref_norm
+                scale = float(np.abs(npz[f"{tag}/out/sample"]).max())
+                assert float(np.abs(s["sample"] - npz[f"{tag}/out/sample"]).max()) < 2.0 ** -5 * scale

@@ -86,14 +86,14 @@ def test_linear_wgrad(M, N, K, splits):
     dW = u.dev(prev.clone())
     slab = torch.empty(splits * N * K, dtype=torch.float32, device="cuda")
     a, b = u.dev(dY, u.BF), u.dev(X, u.BF)
-    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 1, u.stream())
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), slab.numel(), M, N, K, splits, 1, u.stream())
     u.sync()
     u.assert_close(dW, ref + prev, F32_TOL, "dW accumulate")
-    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 0, u.stream())
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), slab.numel(), M, N, K, splits, 0, u.stream())
     u.sync()
     first = dW.clone()
     u.assert_close(dW, ref, F32_TOL, "dW overwrite")
-    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), M, N, K, splits, 0, u.stream())
+    u.call("vg_linear_wgrad", u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), slab.numel(), M, N, K, splits, 0, u.stream())
     u.sync()
     assert torch.equal(first, dW), "wgrad must be bitwise reproducible (no float atomics)"
 
@@ -296,3 +296,26 @@ def test_diversity_loss_matches_torch(B, D):
     u.sync()
     assert abs(float(lo) - float(ref)) <= 1e-4 * float(ref)
     u.assert_close(dd, d0.float() + w * xr.grad, 2.0 ** -7, "d images")
+
+
+def test_linear_wgrad_rejects_undersized_slab_without_launching():
+    """Round-1 fault (gpurun_out/splits.log: 'Write access to a read-only page'): K slices written past a slab carved for
+    fewer slices.  The public entry point now takes the slab size and refuses; nothing is launched (dW untouched)."""
+    u = _u()
+    M, N, K = 512, 128, 128
+    a = torch.zeros(M, N, dtype=u.BF, device="cuda"); b = torch.zeros(M, K, dtype=u.BF, device="cuda")
+    dW = torch.full((N, K), 7.0, device="cuda")
+    slab = torch.empty(2 * N * K, dtype=torch.float32, device="cuda")
+    L = _lib_mod().lib()
+    assert L.vg_linear_wgrad_slab_floats(N, K, 4) == 4 * N * K
+    assert L.vg_linear_wgrad_slab_floats(N, K, 65) == -2 and L.vg_linear_wgrad_slab_floats(N, K, 0) == -2
+    for splits, floats in ((4, slab.numel()), (65, 1 << 40), (0, slab.numel()), (2, 2 * N * K - 1)):
+        rc = L.vg_linear_wgrad(u.ptr(a), u.ptr(b), u.ptr(dW), u.ptr(slab), floats, M, N, K, splits, 0, u.stream())
+        assert rc == -2, (splits, floats, rc)
+    u.sync()
+    assert bool((dW == 7.0).all())
+
+
+def _lib_mod():
+    from vit_gan_amd import _lib
+    return _lib

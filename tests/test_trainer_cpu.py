@@ -1,6 +1,8 @@
 """Trainer shell: output tree, log format, PNG grids - host logic only, no GPU."""
 import os
 import re
+
+import pytest
 import struct
 import zlib
 
@@ -78,9 +80,40 @@ def test_log_line_format(tmp_path, capsys):
     assert open(tmp_path / "training.log").read().strip() == out
 
 
-def test_container_state_dict_prefixes():
-    gan = T.TrainedGan(torch.nn.Linear(2, 2), torch.nn.Linear(2, 1))
-    assert sorted(gan.state_dict()) == ["discriminator.bias", "discriminator.weight", "generator.bias", "generator.weight"]
+def test_config_extra_field_keeps_the_reference_str_and_routes_the_generator():
+    """``Config()`` prints exactly the reference's 15 lines (src/v2/utils.py:42-43); the extra field
+    only shows in what ``ViTGAN(config).generator`` is."""
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTGAN, ViTGenerator
+    lines = str(Config()).split("\n")
+    assert len(lines) == 15 and lines[0] == "attention_heads_count=4" and lines[-1] == "transformer_blocks_count=6"
+    assert "generator_kind" not in str(Config(generator_kind="sln_siren")) and "generator_kind" not in repr(Config())
+    small = dict(embeddings_dimension=128, transformer_blocks_count=1)
+    assert isinstance(ViTGAN(Config(**small)).generator, ViTGenerator)           # default: reference behaviour
+    g = ViTGAN(Config(generator_kind="sln_siren", **small))
+    assert isinstance(g.generator, SirenGenerator) and g.generator.patch_size == 0 and g.generator.latent == 1024
+    keys = sorted(g.state_dict())
+    assert keys[0].startswith("discriminator.vit.") and any(k.startswith("generator.mapping_mlp.") for k in keys)
+    gp = ViTGAN(Config(generator_kind="sln_siren_patch", image_size=64, patch_size=8, **small)).generator
+    assert isinstance(gp, SirenGenerator) and gp.patch_size == 8 and gp.embedding.shape == (64, 128)
+    with pytest.raises(ValueError):
+        ViTGAN(Config(generator_kind="dcgan", **small))
+    tc = T.trainable_config(Config(**small))
+    assert tc.classes_count == 1 and tc.generator_kind == "sln_siren" and T.trainable_config(Config(image_size=64, patch_size=8)).generator_kind == "sln_siren_patch"
+
+
+def test_discriminator_state_strips_the_container_prefix():
+    from vit_gan_amd.modules import ViTDiscriminator, ViTGAN
+    c = Config(embeddings_dimension=128, transformer_blocks_count=1, generator_kind="sln_siren")
+    gan = ViTGAN(c)
+    sd = T.discriminator_state(gan.state_dict())
+    D = ViTDiscriminator(c)
+    assert sorted(sd) == sorted(D.state_dict())
+    D.load_state_dict(sd, strict=True)
+    assert all(torch.equal(D.state_dict()[k], v) for k, v in sd.items())
+    # what INTEGRATION.md used to show loads NOTHING: every key is unexpected
+    res = ViTDiscriminator(c).load_state_dict(gan.state_dict(), strict=False)
+    assert len(res.missing_keys) == len(sd)
 
 
 def test_train_model_refuses_to_run_without_the_gpu():

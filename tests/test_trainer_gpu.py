@@ -8,9 +8,8 @@ import torch
 
 import vit_gan_amd  # noqa: F401
 from vit_gan_amd.config import Config
-from vit_gan_amd.generator import SirenGenerator
-from vit_gan_amd.modules import ViTDiscriminator
-from vit_gan_amd.training import TrainedGan, train_model
+from vit_gan_amd.modules import ViTDiscriminator, ViTGAN
+from vit_gan_amd.training import discriminator_state, train_model, trainable_config
 
 pytestmark = pytest.mark.gpu
 
@@ -32,11 +31,35 @@ def test_train_model_writes_the_reference_artefacts(tmp_path):
     assert lines == [("0", "30.7000"), ("1", "12.2000")]
     # the final checkpoint loads strict=True into freshly built modules and reproduces the trained weights
     state = torch.load(os.path.join(d.save, "final_model.ckpt"), map_location="cpu")
-    c = Config(**cfg).model_copy(update={"classes_count": 1})
-    fresh = TrainedGan(SirenGenerator(image_size=c.image_size, channels=c.input_channels), ViTDiscriminator(c))
+    c = trainable_config(Config(**cfg))
+    assert isinstance(out["gan"], ViTGAN) and c.generator_kind == "sln_siren"
+    fresh = ViTGAN(c)
     fresh.load_state_dict(state, strict=True)
     for k, v in out["gan"].state_dict().items():
         assert torch.equal(v.cpu(), state[k]), k
+    # INTEGRATION.md section 1: the discriminator alone out of a ViTGAN checkpoint, strict=True, same outputs
+    D = ViTDiscriminator(c)
+    D.load_state_dict(discriminator_state(state), strict=True)
+    D = D.cuda().eval()
+    x = torch.rand(4, 3, 32, 32, device="cuda") * 2 - 1
+    with torch.no_grad():
+        assert torch.equal(D(x), out["discriminator"].eval()(x))
+
+
+def test_engine_errors_are_raised_not_swallowed(tmp_path, monkeypatch):
+    """A HIP-side failure must not end as a log line plus a checkpoint (SURVEY 5; VERDICT r1 weak #9)."""
+    from vit_gan_amd import _lib
+    from vit_gan_amd.engine import GanEngine
+
+    def broken_step(self, real):
+        _lib.check(-3, "vg_vit_forward")
+    monkeypatch.setattr(GanEngine, "step", broken_step)
+    with pytest.raises(_lib.HipError):
+        train_model({"epochs": 1, "batch_size": 8, "embeddings_dimension": 128, "transformer_blocks_count": 1},
+                    steps_per_epoch=1, output_base=str(tmp_path))
+    runs = glob.glob(os.path.join(str(tmp_path), "output", "*"))
+    assert runs and not os.path.exists(os.path.join(runs[0], "final_model.ckpt"))
+    assert "HIP engine error" in open(os.path.join(runs[0], "training.log")).read()
 
 
 def test_exceptions_inside_the_loop_are_logged_not_raised(tmp_path):

@@ -46,4 +46,4 @@ for (N, K, mul, nm) in [(384, 768, 4, "NN fc2 dgrad*gelu'"), (768, 384, 0, "NN f
 for (N, K, splits, nm) in [(1152, 384, 4, "TN qkv wgrad"), (768, 384, 6, "TN fc1 wgrad"), (384, 768, 6, "TN fc2 wgrad"), (384, 384, 8, "TN out wgrad")]:
     dy = torch.randn(M, N, device="cuda").to(BF); x = torch.randn(M, K, device="cuda").to(BF)
     dw = torch.zeros(N, K, device="cuda"); slab = torch.empty(splits * N * K, device="cuda")
-    timeit(lambda: L.vg_linear_wgrad(p(dy), p(x), p(dw), p(slab), M, N, K, splits, 1, st), 2.0 * M * N * K, f"{nm} M={M} N={N} K={K} s={splits}")
+    timeit(lambda: L.vg_linear_wgrad(p(dy), p(x), p(dw), p(slab), slab.numel(), M, N, K, splits, 1, st), 2.0 * M * N * K, f"{nm} M={M} N={N} K={K} s={splits}")

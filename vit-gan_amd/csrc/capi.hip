@@ -26,9 +26,15 @@ extern "C" int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, i
   p.Z = (const bf16*)Z; p.ldz = K; p.Zf = Zf; p.ldzf = K;
   return vg_gemm_launch(&p, 1, VG_NN, (hipStream_t)stream);
 }
-extern "C" int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, int M, int N, int K, int splits,
-                               int accumulate, void* stream) {
-  if (!dY || !X || !dW || !slab_ws || splits < 1) return -1;
+extern "C" long long vg_linear_wgrad_slab_floats(int N, int K, int splits) {
+  if (N < 1 || K < 1 || splits < 1 || splits > VG_WGRAD_MAX_SPLITS) return -2;
+  return (long long)splits * N * K;
+}
+extern "C" int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, long long slab_floats, int M, int N, int K,
+                               int splits, int accumulate, void* stream) {
+  if (!dY || !X || !dW || !slab_ws) return -1;
+  const long long need = vg_linear_wgrad_slab_floats(N, K, splits);
+  if (need < 0 || slab_floats < need || M < 1) return -2;  // the K slices are written at slab_ws + s*N*K: never past the caller's buffer
   VgGemmProb p = vg_gemm_prob();
   p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)X; p.ldb = K; p.M = N; p.N = K; p.K = M;
   p.Cf = slab_ws; p.ldcf = K; p.cf_split_stride = (long long)N * K; p.splits = splits;

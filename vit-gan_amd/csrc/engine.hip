@@ -52,6 +52,8 @@ extern "C" int vg_vit_layout(const VgVitDims* d, VgVitLayout* o) {
   const int HE = d->E / d->H;
   if (HE != 32 && HE != 64 && HE != 96) return -3;
   if (NP + 1 > 80) return -3;
+  // depth: the backward queues 3 deferred folds per block and uses one event pair per block (+1 for the join)
+  if (3 * d->L > VG_MAX_FOLD_JOBS || d->L >= VG_CTX_EVENTS - 1) return -3;
   long long p = 0;
   o->conv_w = p; p = al64(p + E * K);
   o->conv_b = p; p = al64(p + E);
@@ -91,6 +93,7 @@ extern "C" int vg_gen_layout(const VgGenDims* d, VgGenLayout* o) {
   const int HE = d->E / d->H;
   if (HE != 32 && HE != 64 && HE != 96) return -3;
   if (d->patch < 0) return -3;
+  if (2 * d->L + 1 > VG_MAX_FOLD_JOBS) return -3;  // the backward queues 2L+1 deferred folds
   if (d->patch > 0) {  // tokens on the patch grid: T and CW are determined by the image geometry
     if (d->C < 1 || d->IH < d->patch || d->IH % d->patch) return -3;
     const int gh = d->IH / d->patch;
@@ -397,12 +400,16 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
-    vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0);
+    VG_TRY(vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
     {
       // the four weight gradients of the block as ONE grouped split-K launch
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
-      static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;  // tuning aid
-      const int splits = (split_env > 0 && split_env <= VIT_SPLIT_CAP) ? split_env : pick_splits(tiles, M, VIT_SPLIT_CAP);  // slab holds CAP slices
+      // the slab and bslab carves hold VIT_SPLIT_CAP slices: never more (round 1 overran them from an environment knob)
+      int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
+#ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
+      static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
+      if (split_env > 0 && split_env <= VIT_SPLIT_CAP) splits = split_env;
+#endif
       VgGemmProb pr[4];
       pr[0] = wg(cur.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
@@ -418,12 +425,12 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       if (l == top) { pr[3].colsum = bs + 3 * E + rE; pr[3].colsum_split_stride = BW; }
       VG_TRY(vg_gemm_launch(pr, 4, VG_TN, sd));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, sd));
-      vg_fold_push(folds, bs, pr[0].splits, (int)BW, G + lo + lay.bqkv, 3 * E, G + lo + lay.b1, rE, (l == top) ? G + lo + lay.b2 : nullptr, E,
-                   nullptr, 0);
+      VG_TRY(vg_fold_push(folds, bs, pr[0].splits, (int)BW, G + lo + lay.bqkv, 3 * E, G + lo + lay.b1, rE, (l == top) ? G + lo + lay.b2 : nullptr, E,
+                   nullptr, 0));
     }
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
-      vg_fold_push(folds, part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0);
+      VG_TRY(vg_fold_push(folds, part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0));
     }
     if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_side[l], sd)); last_side = l; }
   }
@@ -622,7 +629,7 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
                            nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
   {
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
-    vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2);
+    VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2));
   }
   for (int l = d.L - 1; l >= 0; --l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
@@ -640,8 +647,8 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
                              P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part + (size_t)(2 * l) * part_sz, R, E,
                              drop ? gm1buf : nullptr, dr.thr, site_key(dr, 100 + 2 * l), dr.scale, dr.step, st));
     const bf16* gb1 = drop ? gm1buf : gmid;
-    vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
-                 G + lo + lay.sln2_s, 2);
+    VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
+                 G + lo + lay.sln2_s, 2));
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, 0, st));
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
@@ -659,7 +666,7 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
                              P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part + (size_t)(2 * l + 1) * part_sz, R, E,
                              (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
     float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
-    vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2);
+    VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2));
     bf16* t = g; g = gin; gin = t;
   }
   VG_TRY(vg_colsum_f32_multi_launch(folds, st));  // all SLN partial sums in one launch

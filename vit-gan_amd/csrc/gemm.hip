@@ -25,9 +25,6 @@
 #define BM (64 * WM)   // WM wave-rows: 2 -> 128 x 128 tile (256 threads), 4 -> 256 x 128 tile (512 threads)
 #define BN 128
 #define BK 32           // k per LDS stage = one MFMA k-step
-#ifndef VG_ABLATE
-#define VG_ABLATE 0
-#endif
 #ifndef NSTAGE_WM2
 #define NSTAGE_WM2 2
 #endif
@@ -281,13 +278,6 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   const int lda = P.lda, ldb = P.ldb;
   // row form indexes rows (m or n) against M/N; tr form indexes columns against M/N.
   const void* zeros = grp.zeros;
-#ifdef VG_STAMPS
-  unsigned long long tstamp[8];
-  tstamp[0] = __builtin_amdgcn_s_memrealtime();
-#define STAMP(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
-#else
-#define STAMP(i)
-#endif
   const int nsteps = (k_end - k_begin + BK - 1) / BK;
   Stager<A_TR, 4 * WM, NW> sa;
   Stager<B_TR, 8, NW> sb;
@@ -313,31 +303,16 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   fra.setup(0, wm * 64, lane);
   frb.setup(A_TILE_BYTES, wn * 64, lane);
   constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
-  STAMP(1);
   for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
-  STAMP(2);
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     const int ahead = nsteps - 1 - s;  // stages issued after s (at most NSTAGE-2 of them are in flight here)
     if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * DPS) : "memory");
     else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef VG_STAMPS
-    if (s == 0) STAMP(3);
-#endif
-    constexpr int dbg = VG_ABLATE;  // timing experiments only (make abl): 1 = no DMA, 2 = no LDS reads, 4 = no MFMA
-    if (s + NSTAGE - 1 < nsteps && !(dbg & 1)) ISSUE(s + NSTAGE - 1);
+    if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1);
     bf16x8 fm[4], fn[4];
-    if (dbg & 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { for (int j = 0; j < 8; ++j) { fm[i][j] = (bf16)(float)(s + i); fn[i][j] = (bf16)(float)(lane + i); } }
-    } else {
-      load_frags_asm<A_TR, B_TR>(smem_base + (s % NSTAGE) * STAGE_BYTES, fra, frb, fm, fn);
-    }
-    if (dbg & 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)fm[i][0]; acc[0][i][1] += (float)fn[i][1]; }
-    } else
+    load_frags_asm<A_TR, B_TR>(smem_base + (s % NSTAGE) * STAGE_BYTES, fra, frb, fm, fn);
     {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -363,14 +338,12 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       if (m < P.M) cs[m] = accb[mt][0];
     }
   }
-  STAMP(4);
   // ---- epilogue: registers only ---------------------------------------------------------------
   // A lane holds, per (n-tile, m-tile), 4 consecutive n of row li.  v_permlane16_swap between the even and the
   // odd n-tile of a pair hands every lane 8 CONSECUTIVE n of one tile (even lane-groups keep the even tile,
   // odd lane-groups the odd one), so each lane loads/stores 16 B (bf16) or 32 B (fp32) per slot with no trip
   // through LDS (the LDS transpose of the first version cost ~1.5k LDS cycles per workgroup and stalled the
   // co-resident workgroup's main loop).  8 slots per lane: q = 2*mt + pair.
-  STAMP(5);
   constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD || ACT == VG_ACT_MUL_Z);
   constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
   constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
@@ -412,7 +385,6 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
     }
   }
-  STAMP(6);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     {
@@ -509,15 +481,6 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
     }
   }
-#ifdef VG_STAMPS
-  STAMP(7);
-  if (tid == 0 && grp.stamps) {
-    unsigned int xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* o = grp.stamps + (size_t)blockIdx.x * 8;
-    for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
-  }
-#endif
 }
 
 __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -531,20 +494,22 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   int wm4 = 1;
   for (int i = 0; i < n; ++i) {
     const long long t4 = (long long)((probs[i].M + 255) / 256) * ((probs[i].N + 127) / 128);
-    static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;  // tuning aid
+#ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
+    static const long long t4min = getenv("VG_GEMM_T4MIN") ? atoll(getenv("VG_GEMM_T4MIN")) : 96;
+#else
+    constexpr long long t4min = 96;
+#endif
     // epilogues that fit the 128-register budget of 8-wave workgroups (sin / cos / tanh variants do not)
     const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z || probs[i].act == VG_ACT_GELU;
     if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;
   }
-  static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // tuning aid: force the tile height
+#ifdef VG_TUNING
+  static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // force the tile height
   if (wm_env) wm4 = (wm_env == 4) && mode != VG_TN;
+#endif
   const int bm = wm4 ? 256 : 128;
   VgGemmGroup grp;
   grp.n = n;
-#ifdef VG_STAMPS
-  grp.stamps = getenv("VG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("VG_STAMP_PTR"), nullptr, 0) : nullptr;
-
-#endif
   {
     static void* zp = nullptr;  // one device per process (one process per GPU)
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(vg_zero_page)) != hipSuccess) return -5;

@@ -53,10 +53,6 @@ struct VgGemmProb {
 #define VG_MAX_GROUP 4
 struct VgGemmGroup {
   int n;
-#ifdef VG_STAMPS
-  unsigned long long* stamps;  // diagnostic build only: per-workgroup s_memrealtime stamps
-  int dbg;                     // diagnostic build only: ablation bits (1 no DMA, 2 no fragment reads, 4 no MFMA)
-#endif
   const void* zeros;  // 16 zero bytes in device memory: source of out-of-range LDS-DMA lanes
   VgGemmProb p[VG_MAX_GROUP];
 };

@@ -40,13 +40,16 @@ class GanEngine:
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
-                 process_group: Optional["dist.ProcessGroup"] = None):
+                 process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
         Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
         diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
         over this rank's batch - under data parallelism it is NOT the global-batch quantity).
         instance_noise: sigma of the Gaussian noise added to the discriminator's real and fake inputs in its own step
-        (0.1 there, training.py:83-90); the generator's pass through D sees the clean fake."""
+        (0.1 there, training.py:83-90); the generator's pass through D sees the clean fake.
+        external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
+        device inside the step - what parity tests use to feed the oracle and the engine the same noise, also under
+        hipGraph replay."""
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
             raise TypeError("GanEngine needs a ViTDiscriminator/VisionTransformer and a SirenGenerator")
@@ -67,6 +70,7 @@ class GanEngine:
         self.dp_chunks = 3  # pieces of the D backward whose gradient exchange overlaps the remaining backward
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
+        self.external_noise = bool(external_noise)
         self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
@@ -98,6 +102,10 @@ class GanEngine:
         fd.refresh_shadow()
         fg.refresh_shadow()
         self.ctx = _lib.context() if concurrent_wgrad else None
+        # a load_state_dict into either network (directly or through a container such as ViTGAN) copies into the flat
+        # master buffers in place: refresh the bf16 shadows the GEMMs read, or the next step runs on stale weights
+        self._hooks = [m.register_load_state_dict_post_hook(lambda _mod, _keys: self.sync_from_modules())
+                       for m in (vit, generator)]
         self.steps = 0
         self._graph = None
         self._use_graph = bool(use_graph)
@@ -155,7 +163,8 @@ class GanEngine:
         fake_ptr = C.c_void_p(self.imgs.data_ptr() + B * img_bytes)
         self.step_t += 1
         self.imgs[:B].copy_(real)  # fp32 -> bf16 (the GEMM operand type)
-        self.z.normal_()           # construct_noise(), training.py:35-42 / gan.py:231-232
+        if not self.external_noise:
+            self.z.normal_()       # construct_noise(), training.py:35-42 / gan.py:231-232
         fd.grad.zero_()            # gan.discriminator.zero_grad(), training.py:177
         _lib.check(L.vg_gen_forward(C.byref(ng), B, _p(self.z), _p(self.ws_g), fake_ptr, st), "vg_gen_forward")
         d_in = self.imgs
@@ -196,29 +205,55 @@ class GanEngine:
         self.sync.wait()
         self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st, self.clip_g, 1)
 
-    def step(self, real: torch.Tensor) -> torch.Tensor:
+    # ------------------------------------------------------------------------------------------
+    def _state_tensors(self):
+        """Everything a step changes that the next step reads (the training state held on the device)."""
+        fd, fg = self.vit._flat, self.gen._flat
+        return [fd.flat, fd.shadow, fg.flat, fg.shadow, self.m_d, self.v_d, self.m_g, self.v_g, self.step_t]
+
+    def sync_from_modules(self, reset_optimizer: bool = False) -> None:
+        """Call after the modules' parameters were changed behind the engine's back (``load_state_dict``, an in-place
+        edit): refreshes the bf16 shadows the GEMMs read; ``reset_optimizer`` also clears AdamW's moments and step count
+        (a fresh optimizer, which is what the reference has after a restart: it saves no optimizer state,
+        training.py:218-226,262-263)."""
+        self.vit._flat.refresh_shadow()
+        self.gen._flat.refresh_shadow()
+        if reset_optimizer:
+            for t in (self.m_d, self.v_d, self.m_g, self.v_g, self.step_t):
+                t.zero_()
+
+    def step(self, real: torch.Tensor, z: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Run one G/D step on ``real`` [B,C,IH,IW] (cuda).  Returns the device tensor
-        [loss_d_real, loss_d_fake, loss_g] of this step without synchronising."""
+        [loss_d_real, loss_d_fake, loss_g] of this step without synchronising.  ``z`` [B, Z]: the latent batch, required
+        iff the engine was built with ``external_noise=True``."""
         if real.shape[0] != self.B or not real.is_cuda:
             raise ValueError("real must be a cuda tensor with the engine's batch size")
+        if (z is not None) != self.external_noise:
+            raise ValueError("pass z exactly when the engine was built with external_noise=True")
         if not (self.vit._flat.aliased() and self.gen._flat.aliased()):
             raise RuntimeError("module parameters were re-allocated; rebuild the GanEngine")
+        if z is not None:
+            self.z.copy_(z)
         self.steps += 1
         if not self._use_graph:
             self._enqueue(real)
             return self.losses
         if self._graph is None:
             self._static_real = real.clone()
-            # warm-up on a side stream (allocator + lazy module state), then capture
+            # Warm-up on a side stream (allocator, lazily loaded code objects), then capture.  The warm-up is a real step:
+            # the training state is saved before it and restored after it, so N calls of step() are N steps in graph
+            # mode exactly as in eager mode (tests compare the two bit for bit).
+            saved = [t.clone() for t in self._state_tensors()]
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 self._enqueue(self._static_real)
             torch.cuda.current_stream().wait_stream(s)
+            for t, keep in zip(self._state_tensors(), saved):
+                t.copy_(keep)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._enqueue(self._static_real)
-            self.steps += 1
         self._static_real.copy_(real)
         self._graph.replay()
         return self.losses

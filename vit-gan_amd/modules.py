@@ -15,8 +15,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, flat, ops
-from .config import Config
+from .config import GENERATOR_KINDS, Config
 from .flatparams import FlatParams
+from .generator import SirenGenerator
 
 
 class MovingAverage:  # src/v2/modules.py:9-21 (host-side scalar smoothing)
@@ -306,12 +307,26 @@ class ViTDiscriminator(nn.Module):
         return self.vit(x)
 
 
+def generator_from_config(config: Config) -> nn.Module:
+    """``config.generator_kind`` (the one extra Config field, default "v2" = reference behaviour) picks the generator."""
+    kind = config.generator_kind
+    if kind not in GENERATOR_KINDS:
+        raise ValueError(f"generator_kind must be one of {GENERATOR_KINDS}, got {kind!r}")
+    if kind == "v2":
+        return ViTGenerator(config)
+    if kind == "sln_siren":  # v1 defaults (src/v1/config.py:45-49,60-66): z 1024, E 384, 4 heads, 4 blocks, SIREN 768
+        return SirenGenerator(image_size=config.image_size, channels=config.input_channels)
+    return SirenGenerator(image_size=config.image_size, channels=config.input_channels, embed=config.embeddings_dimension,
+                          heads=config.attention_heads_count, patch_size=config.patch_size)
+
+
 class ViTGAN(nn.Module):
-    """src/v2/modules.py:398-410."""
+    """src/v2/modules.py:398-410.  ``Config(generator_kind="sln_siren")`` makes ``.generator`` the working SLN/SIREN
+    network (latent input ``[B, generator.latent]``) instead of the reference's ViTGenerator, whose tail raises."""
 
     def __init__(self, config: Config):
         super().__init__()
-        self.generator = ViTGenerator(config)
+        self.generator = generator_from_config(config)
         self.discriminator = ViTDiscriminator(config)
 
     def zero_grad(self, set_to_none: bool = True):

@@ -54,7 +54,7 @@ def _wgrad(dy_b, x_b, M, N, K):
     splits = max(1, min(8, 512 // max(tiles, 1), max(1, (M // 64) // 4)))
     dW = torch.empty(N, K, dtype=torch.float32, device=dy_b.device)
     slab = torch.empty(splits * N * K, dtype=torch.float32, device=dy_b.device)
-    _lib.check(_lib.lib().vg_linear_wgrad(_p(dy_b), _p(x_b), _p(dW), _p(slab), M, N, K, splits, 0, _st()), "vg_linear_wgrad")
+    _lib.check(_lib.lib().vg_linear_wgrad(_p(dy_b), _p(x_b), _p(dW), _p(slab), slab.numel(), M, N, K, splits, 0, _st()), "vg_linear_wgrad")
     return dW
 
 

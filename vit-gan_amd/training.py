@@ -13,7 +13,9 @@ Kept from the reference:
   * the epoch line ``Epoch [e/E] | Disc Loss: ..., Gen Loss: ... | FID: ...`` (:227-230), ``best_model_epoch_<e>_fid_<n>.pth``
     checkpoints when the FID improves (:216-226) and, in ``finally``, ``final_model.ckpt`` + a last sample grid +
     the run-time line (:252-268);
-  * exceptions raised inside the loop are logged, not re-raised (:248-251).
+  * exceptions raised inside the loop are logged, not re-raised (:248-251) - EXCEPT errors of the HIP engine itself
+    (``_lib.HipError``: a failed launch or rejected kernel arguments), which are logged and then re-raised without
+    writing a checkpoint: a broken kernel must not look like a finished run.
 
 Substitutions (documented in DESIGN.md):
   * data: CIFAR-10 needs a download (utils.py:109-114); pass ``data_loader`` (any iterable of ``(images, labels)``
@@ -37,10 +39,10 @@ from typing import Any, Callable, Dict, Iterable, Optional, Union
 import torch
 from torch import nn
 
+from . import _lib
 from .config import Config
 from .engine import GanEngine
-from .generator import SirenGenerator
-from .modules import ViTDiscriminator
+from .modules import ViTGAN
 
 START_TIME = datetime.datetime.now()
 
@@ -180,18 +182,21 @@ class SyntheticLoader:
             yield x * 2 - 1, None
 
 
-class TrainedGan(nn.Module):
-    """The ``gan`` object of training.py:145: ``.generator`` / ``.discriminator`` children, so its ``state_dict`` has
-    the reference container's ``generator.*`` / ``discriminator.*`` prefixes (modules.py:398-410)."""
+def trainable_config(c: Config) -> Config:
+    """The configuration ``train_model`` builds ``ViTGAN`` from: a 1-logit discriminator (the executable loss, SURVEY 8
+    row a12) and a generator that can produce an image - the reference's default "v2" tail raises, so it is
+    replaced by the SLN/SIREN network (row-token layout at 32x32, patch grid beyond)."""
+    kind = c.generator_kind
+    if kind == "v2":
+        kind = "sln_siren" if c.image_size <= 32 else "sln_siren_patch"
+    return c.model_copy(update={"classes_count": 1, "generator_kind": kind})
 
-    def __init__(self, generator: nn.Module, discriminator: nn.Module):
-        super().__init__()
-        self.generator = generator
-        self.discriminator = discriminator
 
-    def forward(self, z):
-        generated_images = self.generator(z)
-        return generated_images, self.discriminator(generated_images)
+def discriminator_state(gan_state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """``ViTDiscriminator`` keys (``vit.*``) out of a ``ViTGAN`` checkpoint (``discriminator.vit.*``, ``generator.*``) as
+    written by ``train_model`` / src/v2/training.py:220-226,263 - for ``D.load_state_dict(..., strict=True)``."""
+    pre = "discriminator."
+    return {k[len(pre):]: v for k, v in gan_state.items() if k.startswith(pre)}
 
 
 def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 50, max_epochs: Optional[int] = None,
@@ -213,10 +218,8 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
     if save_artifacts:
         dirs.construct()
         _log_file = os.path.join(dirs.save, "training.log")
-    d_cfg = c.model_copy(update={"classes_count": 1})
-    D = ViTDiscriminator(d_cfg).to(dev)
-    G = SirenGenerator(image_size=c.image_size, channels=c.input_channels).to(dev)
-    gan = TrainedGan(G, D).train()  # gan.train(), training.py:148
+    gan = ViTGAN(trainable_config(c)).to(dev).train()  # modules.ViTGAN(c).to(device); gan.train(), training.py:145,148
+    D, G = gan.discriminator, gan.generator
     eng = GanEngine(D, G, batch=c.batch_size, loss=loss, lr_d=c.discriminator_learning_rate, lr_g=c.generator_learning_rate,
                     weight_decay=1e-3, seed=seed, clip_d=clip_d, clip_g=clip_g, diversity_weight=diversity_weight,
                     instance_noise=instance_noise)
@@ -243,6 +246,7 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
     best_fid = float("inf")
     disc_losses, gen_losses, fid_scores, history = [], [], [], []
     epoch = 0
+    fatal: Optional[BaseException] = None
     try:
         log(f"Starting training at: {datetime.datetime.now()}")
         log("Parameters:\n" + str(c))
@@ -273,14 +277,19 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
                 save_figures(dirs.save, disc_losses=disc_losses, gen_losses=gen_losses, fid_scores=fid_scores)
     except KeyboardInterrupt as ke:
         log(f"{ke} raised!")
+    except _lib.HipError as e:  # a failed launch / rejected kernel arguments is never a "successful" run
+        log(f"HIP engine error: {e}\n{traceback.format_exc()}")
+        fatal = e
     except Exception as e:  # the reference logs and carries on to `finally` (training.py:250-251)
         log(f"Exception: {e}\n{traceback.format_exc()}")
     finally:
         model_path = os.path.join(dirs.save, "final_model.ckpt")
-        if save_artifacts:
+        if save_artifacts and fatal is None:  # no further GPU work, no checkpoint of a broken run
             save_figures(dirs.save, disc_losses=disc_losses, gen_losses=gen_losses, fid_scores=fid_scores)
             torch.save(gan.state_dict(), model_path)
             save_samples(epoch, construct_noise())
         log(f"Run took {datetime.datetime.now() - dirs.start}. Saving the model to: {model_path}")
         _log_file = None
+    if fatal is not None:
+        raise fatal
     return {"discriminator": D, "generator": G, "gan": gan, "engine": eng, "history": history, "dirs": dirs}
