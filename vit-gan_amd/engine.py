@@ -48,7 +48,7 @@ class GanEngine:
         instance_noise: sigma of the Gaussian noise added to the discriminator's real and fake inputs in its own step
         (0.1 there, training.py:83-90); the generator's pass through D sees the clean fake.
         external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
-        device inside the step - what parity tests use to feed the oracle and the engine the same noise, also under
+        device inside the step - what parity tests use to give their CPU checker and the engine the same noise, also under
         hipGraph replay."""
         vit = discriminator.vit if isinstance(discriminator, ViTDiscriminator) else discriminator
         if not isinstance(vit, VisionTransformer) or not isinstance(generator, SirenGenerator):
