@@ -167,6 +167,18 @@ typedef struct VgVitLayout {
 int vg_vit_layout(const VgVitDims* d, VgVitLayout* out); /* host only */
 long long vg_vit_ws_bytes(const VgVitDims* d, int B);   /* host only: activation + scratch workspace */
 
+/* Byte offsets inside the workspace of what a forward saves and a backward leaves behind (host only; used by the parity
+ * tests to teacher-force single encoder blocks with the tensors the kernels produced).  M = B*(NP+1) rows.  Per block l:
+ * X[l] at X + l*M*E*2 (X[L] = trunk output), xn1 / ao / xmid / xn2 likewise, qkv at qkv + l*M*3E*2, z1 (gelu') and a1
+ * (gelu) at + l*M*R*E*2, lse at lse + l*B*H*S*4, mean / rstd at + l*M*4.  Backward scratch, one set per block parity:
+ * the backward of block l reads dL/dX[l+1] from gin[l&1] and writes dL/dX[l] to gin[(l&1)^1]; gmid = dL/d x_mid. */
+typedef struct VgVitWsMap {
+  long long X, xn1, qkv, ao, xmid, xn2, z1, a1, lse, mean1, rstd1, mean2, rstd2;
+  long long gin[2], gmid[2], dqkv[2], dz1[2];
+  long long total;
+} VgVitWsMap;
+int vg_vit_ws_map(const VgVitDims* d, int B, VgVitWsMap* out);
+
 typedef struct VgVitNet {
   VgVitDims d;
   const float* P;   /* fp32 master parameters */
@@ -219,6 +231,15 @@ typedef struct VgGenLayout {
 } VgGenLayout;
 int vg_gen_layout(const VgGenDims* d, VgGenLayout* out);
 long long vg_gen_ws_bytes(const VgGenDims* d, int B);
+/* Workspace introspection for the parity tests (host only), byte offsets; R = B*T rows.  Per block l: s1 / cat / htmp /
+ * s2 / hout at + l*R*E*2, qkv at + l*R*3E*2.  wmod = the mapping output [R,E]; sf = final SLN output; y1 = first SIREN
+ * output, zf1 / zf2 = fp32 SIREN pre-activations.  g[0..2]: gradient buffers of the backward - dL/d h entering block l
+ * (from above) is in g[0] when L-1-l is even, g[2] when odd; g[1] holds dL/d h_tmp of the block being processed.
+ * dw_acc: fp32 [R,E] gradient of the modulation vector, summed over the SLN uses processed so far. */
+typedef struct VgGenWsMap {
+  long long wmod, s1, qkv, cat, htmp, s2, hout, sf, y1, zf1, zf2, g[3], dw_acc, total;
+} VgGenWsMap;
+int vg_gen_ws_map(const VgGenDims* d, int B, VgGenWsMap* out);
 typedef struct VgGenNet {
   VgGenDims d;
   const float* P;
@@ -235,6 +256,12 @@ typedef struct VgGenNet {
 /* z fp32 [B,Z]; img bf16 [B, T*CW]: the flat view of generator.py:66-68 (patch == 0) or NCHW [B,C,IH,IH] (patch > 0). */
 int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream);
 int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream);
+/* The same backward in pieces (data-parallel overlap, and block-by-block parity tests): stage 0 = SIREN output layers +
+ * final SLN, stages 1..L = blocks L-1..0, stage L+1 = learned embedding + mapping Linear.  Calls must cover [0, L+2) in
+ * increasing order on one stream with the same arguments.  After the call that returns stage s (1 <= s <= L) the
+ * gradients from layer0 + (L-s)*layer_stride to the end of the flat buffer are final for this backward. */
+int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, const void* d_img, int stage_begin,
+                           int stage_end, void* stream);
 
 #ifdef __cplusplus
 }

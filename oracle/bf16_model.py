@@ -20,7 +20,8 @@ parameters, the fp32 gradient of the modulation vector stay fp32), forward and b
 
 It is validated two ways: against the fp32 oracle on CPU (tests/test_bf16_model_cpu.py: it must stay within the loose
 bf16 bounds of the first tier, and collapse to the fp32 oracle bit-for-bit when rounding is switched off) and against the
-kernels on the GPU at 2^-7 of max|ref| per tensor (tests/test_net_gpu.py).  Citations: the same reference lines as the
+kernels on the GPU stage by stage, each stage fed the tensors the engine produced for it, at two bf16 ulps of the
+largest element (tests/test_blocks_gpu.py; whole networks are chaotic at the ulp level beyond ~1 block, tests/parity_tiers.py).  Citations: the same reference lines as the
 functions of vit_oracle.py / gen_oracle.py they mirror; kernel sites are named in the comments.
 """
 from __future__ import annotations
@@ -202,77 +203,122 @@ def _ln(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# v2 VisionTransformer (mirrors vit_oracle.vit_forward; engine.hip vg_vit_forward / vg_vit_backward_stages)
+# v2 VisionTransformer (mirrors vit_oracle.vit_forward; engine.hip vg_vit_forward / vg_vit_backward_stages).
+# Split at the tensors the engine keeps between stages (X[l]), so a test can run ONE stage on the engine's own inputs.
 # ---------------------------------------------------------------------------------------------------------------------
-def vit_forward(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.",
-                masks: Optional[Mapping] = None) -> Tensor:
-    masks = masks or {}
+def vit_embed(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.", mask: Optional[Tensor] = None) -> Tensor:
+    """image -> X[0]  (vg_patchify + embedding GEMM with bias / position / dropout epilogue + vg_fill_cls)."""
     B, C, IH, IW = x.shape
-    P, E, H, hd = d.patch, d.embed, d.heads, d.head_dim
+    P, E = d.patch, d.embed
     gh, gw = IH // P, IW // P
     xr = stored(x)  # vg_patchify casts the image to bf16; d_img leaves as bf16
     tiles = xr.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
     wc = shadow(state[prefix + "embedding.conv1.weight"]).reshape(E, C * P * P)
     tok = tiles @ wc.t() + state[prefix + "embedding.conv1.bias"] + state[prefix + "embedding.pos_embedding"]
     cls = state[prefix + "embedding.cls_token"].expand(B, 1, E)
-    h = stored(drop(torch.cat([cls, tok], dim=1), masks.get("embed")))  # dropout after every addend (drop_post = 1)
-    S = h.shape[1]
-    scale = 1.0 / math.sqrt(float(hd))
-    for i in range(d.layers):
-        b = f"{prefix}encoder.{i}."
-        xn1 = stored(_ln(h, state[b + "norm1.weight"], state[b + "norm1.bias"]))
-        wqkv = torch.cat([shadow(state[b + f"attention.{n}.weight"]) for n in ("queries", "keys", "values")], dim=0)
-        bqkv = torch.cat([state[b + f"attention.{n}.bias"] for n in ("queries", "keys", "values")], dim=0)
-        qkv = stored(xn1 @ wqkv.t() + bqkv)
-        q, k, v = (t.reshape(B, S, H, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
-        ao = stored(_Attention.apply(q, k, v, scale).transpose(1, 2).reshape(B, S, E))
-        lin = ao @ shadow(state[b + "attention.out_projection.weight"]).t() + state[b + "attention.out_projection.bias"]
-        xmid = stored(drop(lin, masks.get(("attn", i))) + h)
-        xn2 = stored(_ln(xmid, state[b + "norm2.weight"], state[b + "norm2.bias"]))
-        a1 = _GeluStore.apply(xn2 @ shadow(state[b + "fc1.weight"]).t() + state[b + "fc1.bias"])
-        lin = a1 @ shadow(state[b + "fc2.weight"]).t() + state[b + "fc2.bias"]
-        h = stored(drop(lin, masks.get(("mlp", i))) + xmid)
-    # final LayerNorm on the CLS rows only (they alone reach the classifier), then Linear-Tanh-Linear; the last Linear
-    # reads fp32 weights (vg_head_fc2_kernel)
+    return stored(drop(torch.cat([cls, tok], dim=1), mask))  # dropout after every addend (drop_post = 1)
+
+
+def vit_block(state: Mapping[str, Tensor], h: Tensor, d: VitDims, b: str, m_attn: Optional[Tensor] = None,
+              m_mlp: Optional[Tensor] = None) -> Tensor:
+    """X[l] -> X[l+1]; ``h`` must be a stored tensor (or, when teacher-forcing, ``stored(leaf)``)."""
+    B, S, E = h.shape
+    H, hd = d.heads, d.head_dim
+    xn1 = stored(_ln(h, state[b + "norm1.weight"], state[b + "norm1.bias"]))
+    wqkv = torch.cat([shadow(state[b + f"attention.{n}.weight"]) for n in ("queries", "keys", "values")], dim=0)
+    bqkv = torch.cat([state[b + f"attention.{n}.bias"] for n in ("queries", "keys", "values")], dim=0)
+    qkv = stored(xn1 @ wqkv.t() + bqkv)
+    q, k, v = (t.reshape(B, S, H, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
+    ao = stored(_Attention.apply(q, k, v, 1.0 / math.sqrt(float(hd))).transpose(1, 2).reshape(B, S, E))
+    lin = ao @ shadow(state[b + "attention.out_projection.weight"]).t() + state[b + "attention.out_projection.bias"]
+    xmid = stored(drop(lin, m_attn) + h)
+    xn2 = stored(_ln(xmid, state[b + "norm2.weight"], state[b + "norm2.bias"]))
+    a1 = _GeluStore.apply(xn2 @ shadow(state[b + "fc1.weight"]).t() + state[b + "fc1.bias"])
+    lin = a1 @ shadow(state[b + "fc2.weight"]).t() + state[b + "fc2.bias"]
+    return stored(drop(lin, m_mlp) + xmid)
+
+
+def vit_head(state: Mapping[str, Tensor], h: Tensor, prefix: str = "vit.") -> Tensor:
+    """X[L] -> logits: final LayerNorm on the CLS rows only (they alone reach the classifier), Linear-Tanh-Linear; the
+    last Linear reads fp32 weights (vg_head_fc2_kernel)."""
     hc = stored(_ln(h[:, 0, :], state[prefix + "norm.weight"], state[prefix + "norm.bias"]))
     t = _TanhStore.apply(hc @ shadow(state[prefix + "classifier.fc1.weight"]).t() + state[prefix + "classifier.fc1.bias"])
     return t @ state[prefix + "classifier.fc2.weight"].t() + state[prefix + "classifier.fc2.bias"]
 
 
+def vit_forward(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.",
+                masks: Optional[Mapping] = None) -> Tensor:
+    masks = masks or {}
+    h = vit_embed(state, x, d, prefix, masks.get("embed"))
+    for i in range(d.layers):
+        h = vit_block(state, h, d, f"{prefix}encoder.{i}.", masks.get(("attn", i)), masks.get(("mlp", i)))
+    return vit_head(state, h, prefix)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
-# v1 SLN / SIREN generator (mirrors gen_oracle.gen_forward; engine.hip vg_gen_forward / vg_gen_backward)
+# v1 SLN / SIREN generator (mirrors gen_oracle.gen_forward; engine.hip vg_gen_forward / vg_gen_backward_stages)
 # ---------------------------------------------------------------------------------------------------------------------
-def _sln(state: Mapping[str, Tensor], base: str, h: Tensor, w: Tensor) -> Tensor:
+def _sln(state: Mapping[str, Tensor], base: str, h: Tensor, w: Tensor, taps: Optional[dict] = None) -> Tensor:
     ln = _ln(h, state[base + "layer_norm.weight"], state[base + "layer_norm.bias"])
-    return w * (state[base + "gamma"] * ln + state[base + "beta"])  # norm.hip: wm * (g_s * r + b_s)
+    y = w * (state[base + "gamma"] * ln + state[base + "beta"])  # norm.hip: wm * (g_s * r + b_s)
+    if taps is not None:  # tests: the terms whose sums are the scalar gradients, d gamma = sum(dy w ln), d beta = sum(dy w)
+        y.retain_grad()
+        taps[base] = (y, w.detach(), ln.detach())
+    return y
+
+
+def gen_mapping(state: Mapping[str, Tensor], z: Tensor, d: GenDims) -> Tensor:
+    """z -> modulation vectors w [B, T, E] (bf16 in HBM; gradient summed in fp32 over its 2L+1 uses)."""
+    w = _Mapping.apply(bf(z), shadow(state["mapping_mlp.model.0.0.weight"]), state["mapping_mlp.model.0.0.bias"])
+    return w.view(z.shape[0], d.tokens, d.embed)
+
+
+def gen_embedding(state: Mapping[str, Tensor], B: int, d: GenDims):
+    """The two reads of the learned embedding by block 0: (SLN input from the bf16 shadow, residual from the fp32 master)."""
+    return _EmbeddingUses.apply(state["embedding"].expand(B, d.tokens, d.embed))
+
+
+def gen_block(state: Mapping[str, Tensor], b: str, h_sln: Tensor, h_res: Tensor, w: Tensor, d: GenDims,
+              m_attn: Optional[Tensor] = None, m_mlp: Optional[Tensor] = None, taps: Optional[dict] = None) -> Tensor:
+    """h -> h_out of one TransformerSLN block; for blocks > 0 pass the same stored tensor as h_sln and h_res."""
+    B, T, E = w.shape
+    H, hd = d.heads, d.head_dim
+    s1 = stored(_sln(state, b + "layer_norm_1.", h_sln, w, taps))
+    wqkv = torch.cat([shadow(state[f"{b}msha.attention_heads.{hh}.{n}.weight"]) for n in ("q", "k", "v") for hh in range(H)], dim=0)
+    qkv = stored(s1 @ wqkv.t())
+    q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
+    scale = 1.0 / math.sqrt(float(E))  # softmax(q.k / sqrt(H*hd)), src/v1/attention.py:51,90
+    cat = stored(_Attention.apply(q, k, v, scale).transpose(1, 2).reshape(B, T, E))
+    lin = cat @ shadow(state[b + "msha.output_linear.weight"]).t() + state[b + "msha.output_linear.bias"]
+    htmp = stored(drop(lin, m_attn) + h_res)
+    s2 = stored(_sln(state, b + "layer_norm_2.", htmp, w, taps))
+    lin = s2 @ shadow(state[b + "mlp.model.0.0.weight"]).t() + state[b + "mlp.model.0.0.bias"]
+    return stored(drop(lin, m_mlp) + htmp)
+
+
+def gen_head(state: Mapping[str, Tensor], h: Tensor, w: Tensor, d: GenDims, pos_table: Optional[Tensor] = None,
+             taps: Optional[dict] = None) -> Tensor:
+    """h_L -> token rows [B, T, CW]: final SLN (+ optional position table) and the two SIREN layers."""
+    sf = stored(_sln(state, "sln.", h, w, taps))
+    if pos_table is not None:
+        sf = stored(sf + pos_table)  # vg_add_table rewrites the bf16 tensor in place
+    y = _SirenStore.apply(sf @ shadow(state["output_network.0.linear.weight"]).t() + state["output_network.0.linear.bias"], d.omega0)
+    return _SirenStore.apply(y @ shadow(state["output_network.1.linear.weight"]).t() + state["output_network.1.linear.bias"], d.omega0)
+
+
+def rows_to_image(y: Tensor, d: GenDims) -> Tensor:
+    B = y.shape[0]
+    if d.patch:
+        g, P = d.image // d.patch, d.patch
+        return y.view(B, g, g, d.channels, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, d.channels, d.image, d.image)
+    return y.view(B, d.channels, d.image, d.image)
 
 
 def gen_forward(state: Mapping[str, Tensor], z: Tensor, d: GenDims, masks: Optional[Mapping] = None,
                 pos_table: Optional[Tensor] = None) -> Tensor:
     masks = masks or {}
-    B, T, E, H, hd = z.shape[0], d.tokens, d.embed, d.heads, d.head_dim
-    w = _Mapping.apply(bf(z), shadow(state["mapping_mlp.model.0.0.weight"]), state["mapping_mlp.model.0.0.bias"])
-    w = w.view(B, T, E)
-    h_sln, h_res = _EmbeddingUses.apply(state["embedding"].expand(B, T, E))
-    scale = 1.0 / math.sqrt(float(E))  # softmax(q.k / sqrt(H*hd)), src/v1/attention.py:51,90
+    w = gen_mapping(state, z, d)
+    h_sln, h_res = gen_embedding(state, z.shape[0], d)
     for i in range(d.layers):
-        b = f"transformer_layers.{i}."
-        s1 = stored(_sln(state, b + "layer_norm_1.", h_sln, w))
-        wqkv = torch.cat([shadow(state[f"{b}msha.attention_heads.{hh}.{n}.weight"]) for n in ("q", "k", "v") for hh in range(H)], dim=0)
-        qkv = stored(s1 @ wqkv.t())
-        q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
-        cat = stored(_Attention.apply(q, k, v, scale).transpose(1, 2).reshape(B, T, E))
-        lin = cat @ shadow(state[b + "msha.output_linear.weight"]).t() + state[b + "msha.output_linear.bias"]
-        htmp = stored(drop(lin, masks.get(("attn", i))) + h_res)
-        s2 = stored(_sln(state, b + "layer_norm_2.", htmp, w))
-        lin = s2 @ shadow(state[b + "mlp.model.0.0.weight"]).t() + state[b + "mlp.model.0.0.bias"]
-        h_sln = h_res = stored(drop(lin, masks.get(("mlp", i))) + htmp)
-    sf = stored(_sln(state, "sln.", h_sln, w))
-    if pos_table is not None:
-        sf = stored(sf + pos_table)  # vg_add_table rewrites the bf16 tensor in place
-    y = _SirenStore.apply(sf @ shadow(state["output_network.0.linear.weight"]).t() + state["output_network.0.linear.bias"], d.omega0)
-    y = _SirenStore.apply(y @ shadow(state["output_network.1.linear.weight"]).t() + state["output_network.1.linear.bias"], d.omega0)
-    if d.patch:
-        g, P = d.image // d.patch, d.patch
-        return y.view(B, g, g, d.channels, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, d.channels, d.image, d.image)
-    return y.view(B, d.channels, d.image, d.image)
+        h_sln = h_res = gen_block(state, f"transformer_layers.{i}.", h_sln, h_res, w, d, masks.get(("attn", i)), masks.get(("mlp", i)))
+    return rows_to_image(gen_head(state, h_sln, w, d, pos_table), d)

@@ -33,6 +33,16 @@ class VgVitNet(C.Structure):
                 ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("ctx", c_void_p)]
 
 
+class VgVitWsMap(C.Structure):
+    _fields_ = ([(n, c_ll) for n in ("X", "xn1", "qkv", "ao", "xmid", "xn2", "z1", "a1", "lse", "mean1", "rstd1", "mean2", "rstd2")]
+                + [(n, c_ll * 2) for n in ("gin", "gmid", "dqkv", "dz1")] + [("total", c_ll)])
+
+
+class VgGenWsMap(C.Structure):
+    _fields_ = ([(n, c_ll) for n in ("wmod", "s1", "qkv", "cat", "htmp", "s2", "hout", "sf", "y1", "zf1", "zf2")]
+                + [("g", c_ll * 3), ("dw_acc", c_ll), ("total", c_ll)])
+
+
 class VgGenDims(C.Structure):
     _fields_ = ([(n, c_int) for n in ("Z", "T", "E", "H", "L", "O", "CW")] + [("omega0", c_float)]
                 + [(n, c_int) for n in ("patch", "C", "IH")])
@@ -81,6 +91,9 @@ _SIGNATURES = {
     "vg_ctx_destroy": (c_int, [c_void_p]),
     "vg_vit_layout": (c_int, [C.POINTER(VgVitDims), C.POINTER(VgVitLayout)]),
     "vg_vit_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
+    "vg_vit_ws_map": (c_int, [C.POINTER(VgVitDims), c_int, C.POINTER(VgVitWsMap)]),
+    "vg_gen_ws_map": (c_int, [C.POINTER(VgGenDims), c_int, C.POINTER(VgGenWsMap)]),
+    "vg_gen_backward_stages": (c_int, [C.POINTER(VgGenNet), c_int, P, P, c_int, c_int, P]),
     "vg_vit_forward": (c_int, [C.POINTER(VgVitNet), c_int, P, c_int, P, P, P]),
     "vg_vit_backward": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, P]),
     "vg_vit_backward_stages": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, c_int, c_int, P]),

@@ -259,6 +259,22 @@ extern "C" long long vg_vit_ws_bytes(const VgVitDims* d, int B) {
   return carve_vit(*d, B, nullptr, w);
 }
 
+// Byte offsets of the saved activations / gradient scratch inside the workspace (introspection for the parity tests:
+// they teacher-force each encoder block with the tensors the kernels really produced).
+extern "C" int vg_vit_ws_map(const VgVitDims* d, int B, VgVitWsMap* o) {
+  VgVitLayout lay;
+  if (!d || !o || B < 1 || vg_vit_layout(d, &lay)) return -1;
+  unsigned char* const fake = (unsigned char*)(uintptr_t)(1u << 20);  // never dereferenced
+  VitWs w;
+  o->total = carve_vit(*d, B, fake, w);
+  auto off = [&](const void* p) { return (long long)((const unsigned char*)p - fake); };
+  o->X = off(w.X); o->xn1 = off(w.xn1); o->qkv = off(w.qkv); o->ao = off(w.ao); o->xmid = off(w.xmid); o->xn2 = off(w.xn2);
+  o->z1 = off(w.z1); o->a1 = off(w.a1); o->lse = off(w.lse);
+  o->mean1 = off(w.mean1); o->rstd1 = off(w.rstd1); o->mean2 = off(w.mean2); o->rstd2 = off(w.rstd2);
+  for (int i = 0; i < 2; ++i) { o->gin[i] = off(w.set[i].gin); o->gmid[i] = off(w.set[i].gmid); o->dqkv[i] = off(w.set[i].dqkv); o->dz1[i] = off(w.set[i].dz1); }
+  return 0;
+}
+
 extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws, float* logits,
                               void* stream) {
   if (!net || !img || !ws || !logits || B < 1) return -1;
@@ -528,6 +544,20 @@ extern "C" long long vg_gen_ws_bytes(const VgGenDims* d, int B) {
   return carve_gen(*d, B, nullptr, w);
 }
 
+extern "C" int vg_gen_ws_map(const VgGenDims* d, int B, VgGenWsMap* o) {
+  VgGenLayout lay;
+  if (!d || !o || B < 1 || vg_gen_layout(d, &lay)) return -1;
+  unsigned char* const fake = (unsigned char*)(uintptr_t)(1u << 20);  // never dereferenced
+  GenWs w;
+  o->total = carve_gen(*d, B, fake, w);
+  auto off = [&](const void* p) { return (long long)((const unsigned char*)p - fake); };
+  o->wmod = off(w.wmod); o->s1 = off(w.s1); o->qkv = off(w.qkv); o->cat = off(w.cat); o->htmp = off(w.htmp); o->s2 = off(w.s2);
+  o->hout = off(w.hout); o->sf = off(w.sf); o->y1 = off(w.y1); o->zf1 = off(w.zf1); o->zf2 = off(w.zf2);
+  for (int i = 0; i < 3; ++i) o->g[i] = off(w.g[i]);
+  o->dw_acc = off(w.dw_acc);
+  return 0;
+}
+
 extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* ws, void* img, void* stream) {
   if (!net || !z || !ws || !img || B < 1) return -1;
   const VgGenDims& d = net->d;
@@ -581,8 +611,13 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   return 0;
 }
 
-extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream) {
+// Backward stages: 0 = SIREN output layers + final SLN, 1..L = blocks L-1 .. 0, L+1 = learned embedding + mapping Linear.
+// After a call returning stages up to s (1 <= s <= L) the gradients of blocks >= L-s and of everything behind the blocks
+// (final SLN, SIREN) - a contiguous tail of the flat buffer from layer0 + (L-s)*layer_stride - are final.
+extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, const void* d_img, int stage_begin, int stage_end,
+                                      void* stream) {
   if (!net || !ws || !d_img || !net->G || B < 1) return -1;
+  if (stage_begin < 0 || stage_end > net->d.L + 2 || stage_begin >= stage_end) return -2;
   const VgGenDims& d = net->d;
   VgGenLayout lay;
   VG_TRY(vg_gen_layout(&d, &lay));
@@ -600,6 +635,8 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
   bf16* const gm2buf = w.gm[0];  // g masked for the MLP-branch dropout it meets next
   bf16* const gm1buf = w.gm[1];  // gmid masked for the attention-branch dropout
 
+  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
+  if (stage_begin == 0) {
   // SIREN output layers (siren.py:44-45): y = sin(w0 z)  ->  dz = dy * w0 cos(w0 z)
   const bf16* d_rows = (const bf16*)d_img;
   if (d.patch > 0) {  // NCHW gradient -> token rows, the adjoint of the forward scatter
@@ -623,7 +660,6 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.O * E, p.splits, G + lay.s1_w, (long long)d.O * E, 1, st));
   }
   VG_TRY(lin_dgrad(w.dz1, Pb + lay.s1_w, w.ds, R, d.O, E, 0, nullptr, nullptr, 0.f, st));
-  bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
                            nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
@@ -631,7 +667,11 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2));
   }
+  }  // stage 0
   for (int l = d.L - 1; l >= 0; --l) {
+    const int stage = d.L - l;
+    if (stage >= stage_end) break;
+    if (stage < stage_begin) { bf16* t = g; g = gin; gin = t; continue; }  // the buffers rotate once per block already done
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* h = (l == 0) ? Pb + lay.emb : w.hout + (size_t)(l - 1) * RE;
     const int hb = (l == 0) ? T : 0;
@@ -669,7 +709,8 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2));
     bf16* t = g; g = gin; gin = t;
   }
-  VG_TRY(vg_colsum_f32_multi_launch(folds, st));  // all SLN partial sums in one launch
+  VG_TRY(vg_colsum_f32_multi_launch(folds, st));  // all SLN partial sums queued by this call in one launch
+  if (stage_end < d.L + 2) return 0;
   // learned embedding (generator.py:24-26,62) is broadcast over the batch: its gradient is the batch sum
   VG_TRY(vg_batch_sum_launch(g, w.emb_sum, B, T, E, st));
   VG_TRY(vg_slab_reduce_launch(w.emb_sum, 0, 1, G + lay.emb, (long long)T * E, 1, st));
@@ -683,4 +724,9 @@ extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void*
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
   }
   return 0;
+}
+
+extern "C" int vg_gen_backward(const VgGenNet* net, int B, void* ws, const void* d_img, void* stream) {
+  if (!net) return -1;
+  return vg_gen_backward_stages(net, B, ws, d_img, 0, net->d.L + 2, stream);
 }
