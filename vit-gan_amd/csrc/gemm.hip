@@ -210,6 +210,13 @@ constexpr int vg_gemm_waves() {
   if ((FEAT & (F_RESF | F_REMAP | F_PREF32)) || ACT == VG_ACT_MUL_COS) return 2;
   return WM == 2 ? OCC_WM2 : OCC_WM4;
 }
+// A workgroup processes grp.tpw CONSECUTIVE tiles (same m-panel first: the A panel stays in its XCD's L2).  Between two
+// tiles the DMA of the next tile's first NSTAGE-1 stages is issued BEFORE the current tile's epilogue, so the epilogue's
+// loads and 16-byte stores run under that latency and the next main loop starts on landed data.  (The launcher picks
+// tpw = 1 for this model's shapes - measurements in vg_gemm_launch - so the loop below normally runs once.)
+// vmcnt protocol at the seam: one `s_waitcnt vmcnt(0)` after the
+// epilogue's LOADS and before its first STORE retires the prefetched stages (and those loads); the stores are never
+// waited for by name - the first counted wait that covers them is NSTAGE-1 k-steps into the next tile.
 template <int MODE, int WM, int ACT, int FEAT>
 __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) void vg_gemm_kernel(const VgGemmGroup grp) {
   constexpr int NW = 2 * WM;
@@ -220,18 +227,82 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
 
   // XCD-aware block order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
   // run of tiles so the n-tiles of one m-panel hit the same L2 (bijective for any grid size).
-  int bid;
+  int wg;
   {
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
     const int q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  int pi = 0;
+  const int bid_first = wg * grp.tpw;
+  const int bid_end = min(bid_first + grp.tpw, grp.total);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: per-wave LDS bases stay in SGPRs
+  const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
+  const void* zeros = grp.zeros;
+  bf16x8 ones;
 #pragma unroll
-  for (int i = 1; i < VG_MAX_GROUP; ++i)
-    if (i < grp.n && bid >= grp.p[i].tile_start) pi = i;
-  const VgGemmProb& P = grp.p[pi];
-  // epilogue operands, read from kernarg memory up front (overlaps the prologue DMA latency)
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+
+  // tile -> (problem, origin, K slice)
+  struct Tile { int pi, m0, n0, tn, split, k_begin, k_end; };
+  auto locate = [&](int bid) {
+    Tile t;
+    t.pi = 0;
+#pragma unroll
+    for (int i = 1; i < VG_MAX_GROUP; ++i)
+      if (i < grp.n && bid >= grp.p[i].tile_start) t.pi = i;
+    const VgGemmProb& Q = grp.p[t.pi];
+    const int local = bid - Q.tile_start;
+    const int tiles_mn = Q.tiles_m * Q.tiles_n;
+    t.split = local / tiles_mn;
+    const int r = local - t.split * tiles_mn;
+    const int tm = r / Q.tiles_n;
+    t.tn = r - tm * Q.tiles_n;
+    t.m0 = tm * BM; t.n0 = t.tn * BN;
+    t.k_begin = t.split * Q.k_per_split;
+    t.k_end = min(Q.K, t.k_begin + Q.k_per_split);
+    return t;
+  };
+  Stager<A_TR, 4 * WM, NW> sa;
+  Stager<B_TR, 8, NW> sb;
+  // stages are issued strictly in order (prologue, then one per k-step), so the stagers keep a running k
+#define ISSUE(step, kend)                                                                                \
+  do {                                                                                                   \
+    unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
+    if (sa.k_cur + BK <= (kend)) {                                                                      \
+      sa.issue(_b, wid);                                                                                 \
+      sb.issue(_b + A_TILE_BYTES, wid);                                                                  \
+    } else {                                                                                             \
+      sa.issue_tail(_b, (kend), zeros, wid, lane);                                                       \
+      sb.issue_tail(_b + A_TILE_BYTES, (kend), zeros, wid, lane);                                        \
+    }                                                                                                    \
+  } while (0)
+  // row form indexes rows (m or n) against M/N; tr form indexes columns against M/N.
+  auto prime = [&](const Tile& t) {  // stagers at the tile's origin + the DMA of its first NSTAGE-1 stages
+    const VgGemmProb& Q = grp.p[t.pi];
+    // lane-derived address parts are recomputed per tile from an opaque copy of the lane id: hoisted out of the tile loop
+    // they would be spilled around it, and a spill reload drags a compiler `s_waitcnt vmcnt(0)` into the seam
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    sa.setup(Q.A, Q.lda, t.m0, Q.M, t.k_begin, wid, ln);
+    sb.setup(Q.B, Q.ldb, t.n0, Q.N, t.k_begin, wid, ln);
+    const int n = (t.k_end - t.k_begin + BK - 1) / BK;
+    for (int s = 0; s < NSTAGE - 1 && s < n; ++s) ISSUE(s, t.k_end);
+  };
+  const unsigned smem_base = (unsigned)(unsigned long)(lptr_t)smem;
+  FragAddr<A_TR> fra;
+  FragAddr<B_TR> frb;
+  fra.setup(0, wm * 64, lane);
+  frb.setup(A_TILE_BYTES, wn * 64, lane);
+  constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
+
+  Tile cur = locate(bid_first);
+  prime(cur);
+  bool landed = false;  // the prologue stages of `cur` were retired by the previous tile's epilogue wait
+  for (int bid = bid_first; bid < bid_end; ++bid) {
+  const VgGemmProb& P = grp.p[cur.pi];
+  // epilogue operands, read from kernarg memory up front (overlaps the DMA latency)
   const int eM = P.M, eN = P.N;
   bf16* const eC = P.C; const int eldc = P.ldc;
   bf16* const eC2 = P.C2; const int eldc2 = P.ldc2; const int ec2g = P.c2_gelu_grad;
@@ -244,27 +315,12 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   const float ascale = P.act_scale;
   const int epre = P.pre_f32, rip = P.row_in_per, rop = P.row_out_per, roo = P.row_out_off;
   const unsigned dthr = P.drop_thresh, dkey = vg_drop_key(P.drop_key, P.drop_step); const float dscale = P.drop_scale; const int dpost = P.drop_post;
-
-  const int local = bid - P.tile_start;
-  const int tiles_mn = P.tiles_m * P.tiles_n;
-  const int split = local / tiles_mn;
-  const int t = local - split * tiles_mn;
-  const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int k_begin = split * P.k_per_split;
-  const int k_end = min(P.K, k_begin + P.k_per_split);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: per-wave LDS bases stay in SGPRs
-  const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
-  const int g = lane >> 4, li = lane & 15;
+  const int m0 = cur.m0, n0 = cur.n0, split = cur.split, k_end = cur.k_end;
+  const int nsteps = (k_end - cur.k_begin + BK - 1) / BK;
 
   // TN: bias-gradient column sums ride along (first n-tile, wn == 0 waves)
-  const bool do_cs = (MODE == VG_TN) && P.colsum != nullptr && tn == 0 && wn == 0;
+  const bool do_cs = (MODE == VG_TN) && P.colsum != nullptr && cur.tn == 0 && wn == 0;
   f32x4 accb[4];
-  bf16x8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4];  // [nt][mt]
@@ -273,44 +329,16 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bf16* __restrict__ Ag = P.A;
-  const bf16* __restrict__ Bg = P.B;
-  const int lda = P.lda, ldb = P.ldb;
-  // row form indexes rows (m or n) against M/N; tr form indexes columns against M/N.
-  const void* zeros = grp.zeros;
-  const int nsteps = (k_end - k_begin + BK - 1) / BK;
-  Stager<A_TR, 4 * WM, NW> sa;
-  Stager<B_TR, 8, NW> sb;
-  sa.setup(Ag, lda, m0, P.M, k_begin, wid, lane);
-  sb.setup(Bg, ldb, n0, P.N, k_begin, wid, lane);
-  // stages are issued strictly in order (prologue, then one per k-step), so the stagers keep a running k
-#define ISSUE(step)                                                                                      \
-  do {                                                                                                   \
-    unsigned char* _b = smem + ((step) % NSTAGE) * STAGE_BYTES;                                          \
-    if (sa.k_cur + BK <= k_end) {                                                                       \
-      sa.issue(_b, wid);                                                                                 \
-      sb.issue(_b + A_TILE_BYTES, wid);                                                                  \
-    } else {                                                                                             \
-      sa.issue_tail(_b, k_end, zeros, wid, lane);                                                        \
-      sb.issue_tail(_b + A_TILE_BYTES, k_end, zeros, wid, lane);                                         \
-    }                                                                                                    \
-  } while (0)
   // Per k-step: counted vmcnt (stage s landed, later stages may still fly) -> s_barrier -> DMA for stage s+NSTAGE-1
   // -> ds_read fragments -> 16 MFMAs.  The co-resident workgroups' waves fill the SIMD while this one waits.
-  const unsigned smem_base = (unsigned)(unsigned long)(lptr_t)smem;
-  FragAddr<A_TR> fra;
-  FragAddr<B_TR> frb;
-  fra.setup(0, wm * 64, lane);
-  frb.setup(A_TILE_BYTES, wn * 64, lane);
-  constexpr int DPS = (4 * WM + 8) / NW;  // LDS-DMA instructions per wave per stage: 4 (WM=2) or 3 (WM=4)
-  for (int s = 0; s < NSTAGE - 1 && s < nsteps; ++s) ISSUE(s);
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     const int ahead = nsteps - 1 - s;  // stages issued after s (at most NSTAGE-2 of them are in flight here)
-    if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * DPS) : "memory");
+    if (landed && s < NSTAGE - 1) asm volatile("s_barrier" ::: "memory");  // retired at the seam; epilogue stores may still fly
+    else if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * DPS) : "memory");
     else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1);
+    if (s + NSTAGE - 1 < nsteps) ISSUE(s + NSTAGE - 1, k_end);
     bf16x8 fm[4], fn[4];
     load_frags_asm<A_TR, B_TR>(smem_base + (s % NSTAGE) * STAGE_BYTES, fra, frb, fm, fn);
     {
@@ -324,12 +352,24 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
     }
   }
-#undef ISSUE
+  // ---- seam: next tile's first stages go out before this tile's epilogue ----------------------
+  const bool has_next = bid + 1 < bid_end;
+  Tile nxt = cur;
+  if (has_next) {
+    nxt = locate(bid + 1);
+    asm volatile("s_barrier" ::: "memory");  // every wave has finished its fragment reads of the last step (WAR on the ring)
+    prime(nxt);
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------
   // Problem fields were copied to registers up front (a reference into kernarg memory is re-read after every
   // store), and every global LOAD of the epilogue is issued before the first STORE: vmcnt retires in order, so a
   // load issued behind stores would wait for them.
+  // lane coordinates from an opaque copy of the lane id, per tile (see prime(): nothing lane-derived is carried - and
+  // spilled - across the tile loop except the fragment addresses the main loop itself needs)
+  int lne = lane;
+  asm volatile("" : "+v"(lne));
+  const int g = lne >> 4, li = lne & 15;
   if (MODE == VG_TN && do_cs && g == 0) {
     float* cs = P.colsum + (size_t)split * P.colsum_split_stride;
 #pragma unroll
@@ -355,39 +395,54 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
     if (HAS_REMAP && rip > 0) return (m / rip) * rop + roo + (m % rip);
     return m;
   };
-  f32x4 b0[2], b1[2];
-  bf16x8 pre_bf[PRE_BF ? 8 : 1];
-  f32x4 pre_f0[PRE_F ? 8 : 1], pre_f1[PRE_F ? 8 : 1];
-  if (MODE != VG_TN) {
+  if (MODE != VG_TN && ebias) {
+    // bias: added to the accumulators in their own layout (a lane's 4 consecutive n of tile nt) right away, so its
+    // registers are dead again before the slot loop needs its temporaries
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int n = ncol0 + 32 * pr;
-      b0[pr] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[pr] = b0[pr];
-      if (ebias && n < eN) { b0[pr] = *(const f32x4*)(ebias + n); b1[pr] = *(const f32x4*)(ebias + n + 4); }
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + 16 * nt + 4 * g;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (n < eN) b4 = *(const f32x4*)(ebias + n);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] += b4;
     }
-    if (PRE_BF || PRE_F) {
+  }
+  // The 8 slots are processed in groups of 4 (m-tiles 2h, 2h+1) or 2: the epilogue operands (residual, stored
+  // derivative, fp32 addend) of a group are all loaded before its first store; a group's registers instead of a whole
+  // tile's keep every instantiation inside its register budget (no scratch) now that the stagers and fragment addresses
+  // stay live across the epilogue for the next tile.
+  constexpr int NG = HAS_DROP ? 4 : 2, GS = 8 / NG;  // slot groups; the dropout epilogue (hash temporaries) takes quarters
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int m = mrow0 + 16 * (q >> 1), n = ncol0 + 32 * (q & 1);
-        const bool ok = n < eN && m < eM;
-        if (PRE_BF) {
-          bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
-          else if (eres && ok) zb = *(const bf16x8*)(eres + (unsigned)(out_row(m) * eldr + n));
-          pre_bf[q] = zb;
-        }
-        if (PRE_F) {
-          f32x4 zf0 = {0.f, 0.f, 0.f, 0.f}, zf1 = zf0;
-          if (NEED_ZF) { if (ok) { const float* zp = eZf + (unsigned)(m * eldzf + n); zf0 = *(const f32x4*)zp; zf1 = *(const f32x4*)(zp + 4); } }
-          else if (eresf && ok) { const float* rp = eresf + (unsigned)((m % eper) * eN + n); zf0 = *(const f32x4*)rp; zf1 = *(const f32x4*)(rp + 4); }
-          pre_f0[q] = zf0; pre_f1[q] = zf1;
-        }
+  for (int hf = 0; hf < NG; ++hf) {
+  bf16x8 pre_bf[PRE_BF ? GS : 1];
+  f32x4 pre_f0[PRE_F ? GS : 1], pre_f1[PRE_F ? GS : 1];
+  if (MODE != VG_TN && (PRE_BF || PRE_F)) {
+#pragma unroll
+    for (int qq = 0; qq < GS; ++qq) {
+      const int q = GS * hf + qq;
+      const int m = mrow0 + 16 * (q >> 1), n = ncol0 + 32 * (q & 1);
+      const bool ok = n < eN && m < eM;
+      if (PRE_BF) {
+        bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
+        else if (eres && ok) zb = *(const bf16x8*)(eres + (unsigned)(out_row(m) * eldr + n));
+        pre_bf[qq] = zb;
+      }
+      if (PRE_F) {
+        f32x4 zf0 = {0.f, 0.f, 0.f, 0.f}, zf1 = zf0;
+        if (NEED_ZF) { if (ok) { const float* zp = eZf + (unsigned)(m * eldzf + n); zf0 = *(const f32x4*)zp; zf1 = *(const f32x4*)(zp + 4); } }
+        else if (eresf && ok) { const float* rp = eresf + (unsigned)((m % eper) * eN + n); zf0 = *(const f32x4*)rp; zf1 = *(const f32x4*)(rp + 4); }
+        pre_f0[qq] = zf0; pre_f1[qq] = zf1;
       }
     }
   }
+  // seam wait: the next tile's prefetched stages (and the loads above) - everything issued so far - have landed; the
+  // stores below are not waited for here
+  if (hf == 0 && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int qq = 0; qq < GS; ++qq) {
     {
+      const int q = GS * hf + qq;
       const int mt = q >> 1, pr = q & 1;
       const int m = mrow0 + 16 * mt, n = ncol0 + 32 * pr;
       const f32x4 te = acc[2 * pr][mt], to = acc[2 * pr + 1][mt];
@@ -408,8 +463,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
         *(f32x4*)(dst + 4) = hi;
         continue;
       }
-      float v[8] = {lo[0] + b0[pr][0], lo[1] + b0[pr][1], lo[2] + b0[pr][2], lo[3] + b0[pr][3],
-                    hi[0] + b1[pr][0], hi[1] + b1[pr][1], hi[2] + b1[pr][2], hi[3] + b1[pr][3]};
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       const int mo = out_row(m);
       if (HAS_PREF32 && epre) {
         float* dst = eCf + (unsigned)(mo * eldcf + n);
@@ -436,14 +490,14 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       if (NEED_ZBF) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const float zv = vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
+          const float zv = vg_bf2f(pre_bf[PRE_BF ? qq : 0][r]);
           v[r] *= (ACT == VG_ACT_MUL_GELU_GRAD) ? vg_gelu_grad(zv) : ((ACT == VG_ACT_MUL_Z) ? zv : (1.f - zv * zv));
         }
       } else if (NEED_ZF) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] *= ascale * __cosf(ascale * pre_f0[PRE_F ? q : 0][r]);
-          v[r + 4] *= ascale * __cosf(ascale * pre_f1[PRE_F ? q : 0][r]);
+          v[r] *= ascale * __cosf(ascale * pre_f0[PRE_F ? qq : 0][r]);
+          v[r + 4] *= ascale * __cosf(ascale * pre_f1[PRE_F ? qq : 0][r]);
         }
       } else if (ACT == VG_ACT_GELU) {
 #pragma unroll
@@ -463,11 +517,11 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
       if (HAS_RES && !NEED_ZBF && eres) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += vg_bf2f(pre_bf[PRE_BF ? q : 0][r]);
+        for (int r = 0; r < 8; ++r) v[r] += vg_bf2f(pre_bf[PRE_BF ? qq : 0][r]);
       }
       if (HAS_RESF && !NEED_ZF && eresf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] += pre_f0[PRE_F ? q : 0][r]; v[r + 4] += pre_f1[PRE_F ? q : 0][r]; }
+        for (int r = 0; r < 4; ++r) { v[r] += pre_f0[PRE_F ? qq : 0][r]; v[r + 4] += pre_f1[PRE_F ? qq : 0][r]; }
       }
       if (HAS_DROP && dthr && dpost) {
 #pragma unroll
@@ -481,6 +535,11 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
     }
   }
+  }  // slot groups
+  cur = nxt;
+  landed = has_next;
+  }  // tiles of this workgroup
+#undef ISSUE
 }
 
 __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -539,7 +598,22 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     total += p.tiles_m * p.tiles_n * splits;
     grp.p[i] = p;
   }
-  dim3 grid(total);
+  // Tiles per workgroup (see the kernel's header comment).  Measured on the C2 step (round 2, one MI355X): one tile per
+  // workgroup 6.80 ms/step; two tiles wherever the launch has >= 2 tiles per CU slot (the QKV forward) 6.86; two / three /
+  // four everywhere 8.3 / 10.2 / 11.8 - the hardware's own refill of CU slots already staggers the workgroups of a
+  // multi-round launch, and in the single-round launches of this model (390-780 tiles) fewer, longer workgroups only cost
+  // occupancy.  The product therefore runs one tile per workgroup; the seam is exercised by the tests through the tuning
+  // build (VG_GEMM_TPW) and is the hook for shapes with many rounds of tiles.
+  int tpw = 1;
+#ifdef VG_TUNING
+  {
+    static const int tpw_env = getenv("VG_GEMM_TPW") ? atoi(getenv("VG_GEMM_TPW")) : 0;
+    if (tpw_env > 0) tpw = tpw_env;
+  }
+#endif
+  grp.tpw = tpw;
+  grp.total = total;
+  dim3 grid((total + tpw - 1) / tpw);
   const int act = probs[0].act;
   for (int i = 1; i < n; ++i)
     if (probs[i].act != act) return -4;  // one epilogue per launch

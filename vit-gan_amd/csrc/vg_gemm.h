@@ -53,6 +53,7 @@ struct VgGemmProb {
 #define VG_MAX_GROUP 4
 struct VgGemmGroup {
   int n;
+  int tpw, total;     // consecutive tiles per workgroup; number of tiles of the launch
   const void* zeros;  // 16 zero bytes in device memory: source of out-of-range LDS-DMA lanes
   VgGemmProb p[VG_MAX_GROUP];
 };
