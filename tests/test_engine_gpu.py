@@ -140,7 +140,7 @@ def _bench_like(B, seed=5, d_layers=2, g_layers=2, **kw):
     G = SirenGenerator(layers=g_layers, dropout=0.2).train()
     state = ({k: v.detach().clone() for k, v in D.state_dict().items()}, {k: v.detach().clone() for k, v in G.state_dict().items()})
     opts = dict(batch=B, seed=77, external_noise=True, fuse_real_fake=True, concurrent_wgrad=True)
-    opts.update(kw)
+    opts.update(kw)  # d_dropout / g_dropout = 0.0 switch the fused dropout off
     eng = GanEngine(D.cuda(), G.cuda(), **opts)
     return eng, D, G, state
 
@@ -200,11 +200,15 @@ def _step_masks(u, eng, B, step):
             m[("attn", l)] = mask((n_img, S, d.E), eng.p_d, seed, 1 + 2 * l)
             m[("mlp", l)] = mask((n_img, S, d.E), eng.p_d, seed, 2 + 2 * l)
         return m
-    a = vit_masks(2 * B, eng.seed * 8 + 0)
     gm = {}
     for l in range(g.L):
         gm[("attn", l)] = mask((B, g.T, g.E), eng.p_g, eng.seed * 8 + 7, 100 + 2 * l)
         gm[("mlp", l)] = mask((B, g.T, g.E), eng.p_g, eng.seed * 8 + 7, 101 + 2 * l)
+    if eng.two_stream:  # separate real / fake passes (seeds +0 / +1), the generator's pass through D as two half-batches (+2 / +3)
+        lo, hi = vit_masks(B // 2, eng.seed * 8 + 2), vit_masks(B // 2, eng.seed * 8 + 3)
+        return {"d_real": vit_masks(B, eng.seed * 8 + 0), "d_fake": vit_masks(B, eng.seed * 8 + 1),
+                "d_gen": {k: torch.cat([lo[k], hi[k]], dim=0) for k in lo}, "g": gm}
+    a = vit_masks(2 * B, eng.seed * 8 + 0)
     return {"d_real": {k: v[:B] for k, v in a.items()}, "d_fake": {k: v[B:] for k, v in a.items()},
             "d_gen": vit_masks(B, eng.seed * 8 + 2), "g": gm}
 
@@ -414,3 +418,37 @@ def test_instance_noise_on_the_discriminator_inputs():
     ref = oracle.step(real, eng.z.detach().cpu().clone(), noisy_inputs=(noisy[:B], noisy[B:]))
     got = losses.cpu().tolist()
     assert abs(got[0] - ref["d_real"]) < 2e-2 and abs(got[1] - ref["d_fake"]) < 2e-2 and abs(got[2] - ref["g"]) < 2e-2, (got, ref)
+
+
+def test_two_stream_schedule_is_the_unfused_step():
+    """``two_stream=True`` runs D(real) beside [G, D(fake)] and the generator's pass through D as two half-batches side by
+    side.  It is the reference's own pass structure (two separate D passes): against the single-stream unfused engine the
+    first step's losses are bit-equal (same kernels on the same rows), later ones agree to fp32 reassociation of the two
+    gradient buffers; eager and hipGraph replay of the two-stream step are bit-equal; and it matches the step model."""
+    import gpu_util as u
+    from oracle import gen_oracle as go, step_oracle as so, vit_oracle as vo
+    B, n = 8, 3
+    runs = {}
+    for name, kw in (("unfused", dict(fuse_real_fake=False, use_graph=False, concurrent_wgrad=False)),
+                     ("two_stream", dict(two_stream=True, use_graph=False)),
+                     ("two_stream_graph", dict(two_stream=True, use_graph=True))):
+        eng, D, G, _ = _bench_like(B, d_dropout=0.0, g_dropout=0.0, **kw)
+        runs[name] = _run_steps(eng, n, B)
+    (l_u, s_u), (l_t, s_t), (l_g, s_g) = runs["unfused"], runs["two_stream"], runs["two_stream_graph"]
+    assert torch.equal(l_t, l_g) and all(torch.equal(a, b) for a, b in zip(s_t, s_g)), "graph replay != eager (two-stream)"
+    assert torch.equal(l_t[0, :2], l_u[0, :2]), (l_t[0], l_u[0])       # D losses of step 0: identical arithmetic
+    assert float((l_t - l_u).abs().max()) < 2e-3, (l_t, l_u)
+    close = float(((s_t[0] - s_u[0]).abs() < 2e-5).float().mean())
+    assert close > 0.98 and float((s_t[0] - s_u[0]).abs().max()) < 3.1e-3, close   # sign flips of noise-level gradients only
+    # with dropout on: the model with the two-stream passes' own masks (pass seeds 0 / 1, half-batch passes 2 / 3)
+    eng, D, G, (d_state, g_state) = _bench_like(B, two_stream=True, use_graph=True)
+    model = so.GanStepOracle(d_state, g_state, vo.VitDims(layers=2, classes=1), go.GenDims(layers=2), faithful=True)
+    g = torch.Generator().manual_seed(9)
+    real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    z = torch.randn(B, 1024, generator=g)
+    got = eng.step(real.cuda(), z.cuda()).cpu().tolist()
+    torch.cuda.synchronize()
+    m = _step_masks(u, eng, B, 1)
+    ref = model.step(real, z, masks=m)
+    for x, k in zip(got, ("d_real", "d_fake", "g")):
+        assert abs(x - ref[k]) < 1e-3, (k, got, ref)

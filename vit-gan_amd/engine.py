@@ -40,13 +40,19 @@ class GanEngine:
                  d_dropout: Optional[float] = None, g_dropout: Optional[float] = None, seed: int = 0,
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
-                 process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False):
+                 process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
+                 two_stream: bool = False):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
         Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
         diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
         over this rank's batch - under data parallelism it is NOT the global-batch quantity).
         instance_noise: sigma of the Gaussian noise added to the discriminator's real and fake inputs in its own step
         (0.1 there, training.py:83-90); the generator's pass through D sees the clean fake.
+        two_stream: run the step as two concurrent chains on two HIP streams (single GPU only) - D(real) forward/backward
+        beside [G forward, D(fake) forward/backward], which is also the reference's own pass structure (two separate D
+        passes, training.py:182-194), then the generator's pass through D as two half-batches side by side.  Kernels of the
+        two chains are in different phases (a GEMM main loop next to another GEMM's epilogue, a LayerNorm next to a
+        GEMM), which the single-chain step cannot be: every launch of this model covers the chip about once.
         external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
         device inside the step - what parity tests use to give their CPU checker and the engine the same noise, also under
         hipGraph replay."""
@@ -71,6 +77,7 @@ class GanEngine:
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
+        self.two_stream = bool(two_stream)
         self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
@@ -81,9 +88,19 @@ class GanEngine:
             raise ValueError("generator output does not match the discriminator's image shape")
         L = _lib.lib()
         B, dev = self.B, self.dev
+        if self.two_stream:
+            if self.world > 1:
+                raise ValueError("two_stream is a single-GPU schedule (the data-parallel path overlaps the exchange instead)")
+            if B % 2:
+                raise ValueError("two_stream needs an even batch")
+            self.fuse = False
         nD = 2 * B if self.fuse else B
         self.Kc = d.Kc
         self.ws_d = torch.empty(L.vg_vit_ws_bytes(C.byref(d), nD), dtype=torch.uint8, device=dev)
+        if self.two_stream:  # second chain: its own workspace, gradient buffer and stream
+            self.ws_d2 = torch.empty(L.vg_vit_ws_bytes(C.byref(d), B), dtype=torch.uint8, device=dev)
+            self.grad2 = torch.zeros_like(vit._flat.grad)
+            self.side = torch.cuda.Stream(device=dev)
         self.ws_g = torch.empty(L.vg_gen_ws_bytes(C.byref(g), B), dtype=torch.uint8, device=dev)
         self.imgs = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)  # [real ; fake]
         self.dfake = torch.empty(B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)
@@ -117,12 +134,17 @@ class GanEngine:
         # masks: host seed (fixed per pass) mixed on the device with the step counter, so a replayed hipGraph
         # still draws fresh masks; pass A = [real;fake] (or real), B = fake, C = generator pass through D
         step_ptr = self.step_t.data_ptr()
-        mk = lambda i: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(),  # noqa: E731
-                                     self.p_d, self.seed * 8 + i, step_ptr, self.ctx)
-        tab = self.gen.fourier_table
-        ng = _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr,
-                           None if tab is None else tab.data_ptr())
-        return (mk(0), mk(1), mk(2)), ng
+        mk = lambda i, g=None, ctx=True: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(),  # noqa: E731
+                                                       (fd.grad if g is None else g).data_ptr(), self.p_d, self.seed * 8 + i, step_ptr,
+                                                       self.ctx if ctx else None)
+        if self.two_stream:  # chains run side by side: no third stream inside a pass; the fake chain accumulates into grad2
+            return (mk(0, ctx=False), mk(1, self.grad2, ctx=False), mk(2, ctx=False), mk(3, ctx=False)), self._gen_net(step_ptr)
+        return (mk(0), mk(1), mk(2)), self._gen_net(step_ptr)
+
+    def _gen_net(self, step_ptr):
+        fg, tab = self.gen._flat, self.gen.fourier_table
+        return _lib.VgGenNet(self.gen._dims, fg.flat.data_ptr(), fg.shadow.data_ptr(), fg.grad.data_ptr(), self.p_g, self.seed * 8 + 7, step_ptr,
+                             None if tab is None else tab.data_ptr())
 
     def _d_backward(self, nd, n_img: int, dl, want_w: int, dimg, st) -> None:
         """D backward; under data parallelism in ``dp_chunks`` pieces (head + upper blocks first) so that the all-reduce
@@ -153,8 +175,76 @@ class GanEngine:
         _lib.check(L.vg_gan_loss(C.c_void_p(self.logits.data_ptr() + off), C.c_void_p(self.dlogits.data_ptr() + off),
                                  C.c_void_p(self.losses.data_ptr() + 4 * slot), n * self.Kc, self.kind, role, 1.0, st), "vg_gan_loss")
 
+    def _enqueue_two_stream(self, real: torch.Tensor) -> None:
+        """The step as two concurrent chains (see ``two_stream``).  Everything is enqueued from this thread; the second chain
+        forks from and joins the current stream through events, so the whole step is still one capturable graph."""
+        L, B = _lib.lib(), self.B
+        s0, s1 = torch.cuda.current_stream(), self.side
+        st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
+        (nd_a, nd_b, nd_c, nd_d), ng = self._nets()
+        fd, fg = self.vit._flat, self.gen._flat
+        img_bytes = self.imgs[0].numel() * 2
+        Kc4 = 4 * self.Kc
+        off_img = lambda t, n: C.c_void_p(t.data_ptr() + n * img_bytes)  # noqa: E731
+        off_log = lambda t, n: C.c_void_p(t.data_ptr() + n * Kc4)       # noqa: E731
+        fake_ptr = off_img(self.imgs, B)
+        self.step_t += 1
+        self.imgs[:B].copy_(real)
+        if not self.external_noise:
+            self.z.normal_()
+        fd.grad.zero_()
+        self.grad2.zero_()
+        d_in = self.imgs
+        s1.wait_stream(s0)
+        # chain 1 (side stream): G forward, then D on the fake batch (weight gradients into grad2)
+        with torch.cuda.stream(s1):
+            _lib.check(L.vg_gen_forward(C.byref(ng), B, _p(self.z), _p(self.ws_g), fake_ptr, st1), "vg_gen_forward")
+            if self.inst_sigma > 0.0:
+                self.inoise[B:].normal_()
+                torch.add(self.imgs[B:].float(), self.inoise[B:], alpha=self.inst_sigma, out=self.inoise[B:])
+                self.imgs_noisy[B:].copy_(self.inoise[B:])
+            src = off_img(self.imgs_noisy if self.inst_sigma > 0.0 else self.imgs, B)
+            _lib.check(L.vg_vit_forward(C.byref(nd_b), B, src, 1, _p(self.ws_d2), off_log(self.logits, B), st1), "vg_vit_forward")
+            _lib.check(L.vg_gan_loss(off_log(self.logits, B), off_log(self.dlogits, B), C.c_void_p(self.losses.data_ptr() + 4), B * self.Kc,
+                                     self.kind, 1, 1.0, st1), "vg_gan_loss")
+            _lib.check(L.vg_vit_backward(C.byref(nd_b), B, _p(self.ws_d2), off_log(self.dlogits, B), None, 1, st1), "vg_vit_backward")
+        # chain 0 (this stream): D on the real batch
+        if self.inst_sigma > 0.0:
+            self.inoise[:B].normal_()
+            torch.add(self.imgs[:B].float(), self.inoise[:B], alpha=self.inst_sigma, out=self.inoise[:B])
+            self.imgs_noisy[:B].copy_(self.inoise[:B])
+            d_in = self.imgs_noisy
+        _lib.check(L.vg_vit_forward(C.byref(nd_a), B, _p(d_in), 1, _p(self.ws_d), _p(self.logits), st0), "vg_vit_forward")
+        self._loss(0, B, 0, 0, st0)
+        _lib.check(L.vg_vit_backward(C.byref(nd_a), B, _p(self.ws_d), _p(self.dlogits), None, 1, st0), "vg_vit_backward")
+        s0.wait_stream(s1)
+        fd.grad.add_(self.grad2)  # the two passes accumulate into one .grad in the reference (training.py:184,194)
+        self._adamw(fd, self.m_d, self.v_d, self.hyp["lr_d"], st0, self.clip_d, 0)
+        fg.grad.zero_()
+        # generator's pass through the updated D: two half-batches side by side (no weight gradients, nothing shared)
+        h = B // 2
+        s1.wait_stream(s0)
+        with torch.cuda.stream(s1):
+            _lib.check(L.vg_vit_forward(C.byref(nd_d), h, off_img(self.imgs, B + h), 1, _p(self.ws_d2), off_log(self.logits, h), st1), "vg_vit_forward")
+        _lib.check(L.vg_vit_forward(C.byref(nd_c), h, fake_ptr, 1, _p(self.ws_d), _p(self.logits), st0), "vg_vit_forward")
+        s0.wait_stream(s1)
+        self._loss(0, B, 2, 2, st0)  # one mean over the whole batch
+        s1.wait_stream(s0)
+        with torch.cuda.stream(s1):
+            _lib.check(L.vg_vit_backward(C.byref(nd_d), h, _p(self.ws_d2), off_log(self.dlogits, h), off_img(self.dfake, h), 0, st1), "vg_vit_backward")
+        _lib.check(L.vg_vit_backward(C.byref(nd_c), h, _p(self.ws_d), _p(self.dlogits), _p(self.dfake), 0, st0), "vg_vit_backward")
+        s0.wait_stream(s1)
+        if self.div_w != 0.0:
+            Dn = self.dfake[0].numel()
+            _lib.check(L.vg_diversity_loss(fake_ptr, _p(self.dfake), _p(self.div_loss), _p(self.div_scratch), B, Dn, self.div_w, st0),
+                       "vg_diversity_loss")
+        _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st0), "vg_gen_backward")
+        self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st0, self.clip_g, 1)
+
     def _enqueue(self, real: torch.Tensor) -> None:
         """Enqueue one full step on the current stream (no host sync)."""
+        if self.two_stream:
+            return self._enqueue_two_stream(real)
         L, B = _lib.lib(), self.B
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         (nd, nd_b, nd_c), ng = self._nets()
