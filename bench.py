@@ -75,12 +75,28 @@ def gen_flops_per_image(latent, tokens, embed, layers, siren_hidden, out_feature
     return 2 * Z * T * E + layers * per_layer + 2 * T * E * O + 2 * T * O * out_features
 
 
+PEAK_HBM_GBS = 8000.0      # HBM3E, MI355X_MICROARCH.md "Chip-level parameters" (6.3 TB/s is what a streaming copy reaches)
+TRAFFIC_FILE = "profiles/r02_gemm_pmc_traffic.json"
+
+
 def gemm_roofline(torch, B):
-    """Dominant kernel of the step (rocprof: profiles/r01_bench_b256_kernel_stats.csv) = vg_gemm_kernel<1, 4, 0, 0>,
-    the input-gradient GEMM; timed at its heaviest shape, the QKV dgrad of the fused real+fake pass:
-    dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.  Average launch duration is measured live with HIP
-    events on the stream the kernel runs on; achieved = algorithmic FLOPs (2*M*N*K) / that duration.
-    `traffic` = HBM bytes per launch of this kernel from the PMC passes stored under profiles/."""
+    """Dominant kernel of the step (rocprof: profiles/r02_bench_b256_single_stream_kernel_stats.csv) =
+    vg_gemm_kernel<1, 4, 0, 0>, the input-gradient GEMM, timed at its heaviest shape, the QKV dgrad of the fused real+fake
+    pass: dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.
+
+    Duration = PER-DISPATCH time: every launch sits between its own pair of HIP events on the stream the kernel runs on
+    (an event completes only when the launch before it has finished, so consecutive launches do not overlap inside a pair:
+    this is what rocprofv3's per-dispatch AverageNs measures; profiles/r02_roofline_gemm_kernel_stats.csv is the same
+    command under the profiler).  The back-to-back figure (one event pair around all launches, ramp-down of one launch
+    under the ramp-up of the next) is reported beside it.
+
+    Bound: the shape's algorithmic intensity, 2MNK / 2(MN + NK + MK) = 285 flop/B, is just under the chip's ridge
+    (2500 TFLOP/s / 8 TB/s = 312 flop/B): by the roofline model it is HBM-bound, narrowly, and `frac` is taken against
+    the 8 TB/s HBM peak; the fraction of the dense bf16 MFMA peak is reported too (`mfma`).  What actually limits the
+    kernel is neither roof but the L2->LDS staging rate.
+    `traffic` = HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gfx950
+    FETCH_SIZE x2 correction), read from the committed summary named in `traffic_source` - PMC counters cannot be read
+    from inside the process."""
     import ctypes as C
     from vit_gan_amd import _lib
     M, N, K = 2 * B * 65, 1152, 384  # dY [M,N], W [N,K], dX [M,K]
@@ -94,27 +110,43 @@ def gemm_roofline(torch, B):
         _lib.check(L.vg_linear_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, N, K, 0, None, None, 0.0, st), "vg_linear_dgrad")
     for _ in range(5):
         run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 50
-    e0.record()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for e0, e1 in ev:       # per-dispatch: one event pair per launch
+        e0.record()
+        run()
+        e1.record()
+    torch.cuda.synchronize()
+    per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    ms = sum(per) / reps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()             # back-to-back: one pair around all launches
     for _ in range(reps):
         run()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    traffic = None
+    ms_b2b = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * N * K
+    byts = 2 * (M * N + N * K + M * K)
+    tf = flops / (ms * 1e-3) / 1e12
+    gbs = byts / (ms * 1e-3) / 1e9
+    traffic, source = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             rec = json.load(f)["kernels"]["NN qkv dgrad"]
         if rec["out_rows_cols_reduction"] == [M, K, N]:
-            traffic = rec["hbm_bytes_per_launch"]
+            traffic, source = rec["hbm_bytes_per_launch"], TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_bench.py)"
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "kernel": "vg_gemm_kernel<1, 4, 0, 0> = NN input-gradient GEMM, 256x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
-            "algorithmic_flops_per_launch": 2.0 * M * N * K, "algorithmic_bytes_per_launch": 2 * (M * N + N * K + M * K),
-            "avg_launch_us": round(ms * 1e3, 2)}
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": traffic, "traffic_source": source,
+            "mfma": {"achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)},
+            "intensity_flop_per_byte": round(flops / byts, 1), "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+            "kernel": "vg_gemm_kernel<1, 4, 0, 0> = NN input-gradient GEMM, 256x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+            "avg_launch_us": round(ms * 1e3, 2), "median_launch_us": round(per[reps // 2] * 1e3, 2), "min_launch_us": round(per[0] * 1e3, 2),
+            "back_to_back_us": round(ms_b2b * 1e3, 2), "timing": "per-dispatch HIP event pairs on the kernel's stream, 50 launches"}
 
 
 def main():
@@ -123,6 +155,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 256 for C2, 128 for C4 / C5)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: FIXED global batch split over the ranks (config C3 of BASELINE.json: --global-batch 2048 -> "
+                         "1024 / 512 / 256 per GPU at 2 / 4 / 8 GPUs); default 0 = weak scaling, the per-GPU batch is fixed")
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 (default, the metric's configuration): 32x32 patch 4 E=384 4 heads, v1 row-token generator; "
                          "c4: 64x64 patch 8 E=512 8 heads; c5: 128x128 patch 16 E=768 12 heads (bf16 attention) - "
@@ -177,6 +212,10 @@ def main():
            "c4": dict(image=64, patch=8, embed=512, heads=8, batch=128, gpatch=8),
            "c5": dict(image=128, patch=16, embed=768, heads=12, batch=128, gpatch=16)}[args.workload]
     B = args.batch or geo["batch"]
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        B = args.global_batch // world
     IMG = geo["image"]
     torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
     cfg = Config(embeddings_dimension=geo["embed"], attention_heads_count=geo["heads"], transformer_blocks_count=6, mlp_ratio=2,
@@ -233,7 +272,7 @@ def main():
         out = {
             "metric": "images/sec (G+D step) ViTGAN 32x32 patch4 dim384" if args.workload == "c2" else f"images/sec (G+D step) ViTGAN {args.workload} shape", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": {"c2": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
                                           "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
                                     "c4": "C4 shape: 3x64x64, patch 8 (65 tokens), E=512, 8 heads, 6 blocks ViT discriminator + patch-grid "

@@ -38,6 +38,14 @@ def _worker(rank, world, port, out):
         ref = torch.arange(1000, dtype=torch.float32)
         tot = sum(r + 1 for r in range(world))
         assert torch.equal(flat[100:900], ref[100:900] * tot) and torch.equal(flat[:100], ref[:100] * (rank + 1))
+        # (a') bf16-compressed exchange: the sum of the bf16-rounded contributions, written back to the fp32 buffer
+        flat = (torch.arange(1000, dtype=torch.float32) * 0.37 + 0.011) * (rank + 1)
+        want = sum(((torch.arange(1000, dtype=torch.float32) * 0.37 + 0.011) * (r + 1)).to(torch.bfloat16) for r in range(world))
+        sync.reduce_range(flat, 200, 800, compress=True)
+        sync.wait()
+        untouched = (torch.arange(1000, dtype=torch.float32) * 0.37 + 0.011) * (rank + 1)
+        assert torch.equal(flat[200:800], want[200:800].float()), "bf16 exchange"
+        assert torch.equal(flat[:200], untouched[:200]) and torch.equal(flat[800:], untouched[800:])
         # (b) sharded D gradient == global-batch gradient
         d = vo.VitDims(embed=128, heads=4, layers=1, classes=1)
         st = {k: v.clone().requires_grad_(True) for k, v in vo.init_vit_state(d, 7).items()}

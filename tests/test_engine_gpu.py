@@ -286,28 +286,38 @@ def _dp_worker(rank, world, port, out):
         from vit_gan_amd.engine import GanEngine
         from vit_gan_amd.generator import SirenGenerator
         from vit_gan_amd.modules import ViTDiscriminator
-        torch.manual_seed(0)  # identical init on every rank
         B = 4
-        D = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, dropout_rate=0.1, batch_size=B,
-                                    transformer_blocks_count=4)).cuda().train()
-        G = SirenGenerator(embed=128, layers=2, siren_hidden=256).cuda().train()
-        eng = GanEngine(D, G, batch=B, seed=100 + rank)
-        assert eng.world == world and eng.sync.overlap
-        torch.manual_seed(50 + rank)  # different data / noise per rank
-        for _ in range(3):
-            real = torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1
-            losses = eng.step(real)
-        torch.cuda.synchronize()
-        w = D.vit._flat.flat.detach().cpu()
-        gw = G._flat.flat.detach().cpu()
-        gsum = D.vit._flat.grad.detach().cpu()
+
+        def run(dp_chunks, compress):
+            torch.manual_seed(0)  # identical init on every rank (and for every exchange variant)
+            D = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, dropout_rate=0.1, batch_size=B,
+                                        transformer_blocks_count=4)).cuda().train()
+            G = SirenGenerator(embed=128, layers=3, siren_hidden=256).cuda().train()
+            eng = GanEngine(D, G, batch=B, seed=100 + rank, compress_mapping_grad=compress)
+            eng.dp_chunks = dp_chunks
+            assert eng.world == world and eng.sync.overlap
+            torch.manual_seed(50 + rank)  # different data / noise per rank
+            for _ in range(3):
+                real = torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1
+                losses = eng.step(real)
+            torch.cuda.synchronize()
+            return (D.vit._flat.flat.detach().cpu(), G._flat.flat.detach().cpu(), D.vit._flat.grad.detach().cpu(), losses.cpu(),
+                    G._flat.grad.detach().cpu())
+        w, gw, gsum, losses, ggrad = run(3, False)         # D and G backward in 3 pieces, exchange overlapped
+        w1, gw1, _, _, ggrad1 = run(1, False)              # one all-reduce per network after its whole backward
+        w2, gw2, _, _, ggrad2 = run(3, True)               # + mapping-layer gradient exchanged as bf16
         gather = [None] * world
-        dist.all_gather_object(gather, (w, gw, gsum, losses.cpu()))
+        dist.all_gather_object(gather, (w, gw, gsum, losses, gw2))
         if rank == 0:
-            ok = all(torch.equal(gather[0][0], g[0]) and torch.equal(gather[0][1], g[1]) and torch.equal(gather[0][2], g[2]) for g in gather[1:])
+            ok = all(torch.equal(gather[0][0], g[0]) and torch.equal(gather[0][1], g[1]) and torch.equal(gather[0][2], g[2])
+                     and torch.equal(gather[0][4], g[4]) for g in gather[1:])
             fin = all(torch.isfinite(g[3]).all() for g in gather) and torch.isfinite(w).all()
             differ = not torch.equal(gather[0][3], gather[1][3])  # different shards -> different local losses
-            out.put(("ok", (ok, bool(fin), differ)))
+            staged_equal = torch.equal(w, w1) and torch.equal(gw, gw1) and torch.equal(ggrad, ggrad1)
+            # bf16 exchange of the mapping gradient: same update direction for all but noise-level entries
+            rel = float((ggrad2 - ggrad).abs().max()) / float(ggrad.abs().max())
+            compressed_close = rel < 2.0 ** -7 and float((gw2 - gw).abs().max()) < 3.1e-3 and not torch.equal(ggrad2, ggrad)
+            out.put(("ok", (ok, bool(fin), differ, staged_equal, compressed_close, rel)))
     except Exception as e:
         import traceback
         out.put(("err", f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()[-1500:]}"))
@@ -317,8 +327,10 @@ def _dp_worker(rank, world, port, out):
 
 @pytest.mark.timeout(600)
 def test_two_rank_data_parallel_engine_on_one_gpu():
-    """world_size 2 through the real engine path (staged D backward + overlapped ranged all-reduce on a side
-    stream + 1/world folded into AdamW): replicas must stay bit-identical, gradients must be the all-reduced sum."""
+    """world_size 2 through the real engine path (staged D and G backward + overlapped ranged all-reduce on a side
+    stream + 1/world folded into AdamW): replicas must stay bit-identical, gradients must be the all-reduced sum; the
+    staged exchange must equal one all-reduce per network bitwise; the bf16-compressed mapping gradient stays within
+    2^-7 of the fp32 exchange."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -333,9 +345,11 @@ def test_two_rank_data_parallel_engine_on_one_gpu():
     for p in procs:
         p.join(timeout=120)
     assert status == "ok", val
-    same, finite, differ = val
+    same, finite, differ, staged_equal, compressed_close, rel = val
     assert same, "replicas diverged: weights / reduced gradients differ between ranks"
     assert finite and differ
+    assert staged_equal, "staged (overlapped) D / G exchange must equal the single all-reduce bit for bit"
+    assert compressed_close, f"bf16 exchange of the mapping gradient: relative deviation {rel}"
 
 
 def test_engine_step_with_patch_grid_generator_at_c4_shape():
@@ -452,3 +466,50 @@ def test_two_stream_schedule_is_the_unfused_step():
     ref = model.step(real, z, masks=m)
     for x, k in zip(got, ("d_real", "d_fake", "g")):
         assert abs(x - ref[k]) < 1e-3, (k, got, ref)
+
+
+def _rccl_worker(port, out):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        flat = torch.arange(4096, dtype=torch.float32, device="cuda")
+        comm = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):            # the exact call pattern of GradSync.reduce_range (overlap path)
+            comm.wait_event(ready)
+            work = dist.all_reduce(flat[1024:3072], op=dist.ReduceOp.SUM, async_op=True)
+            half = flat[:1024].to(torch.bfloat16)
+            dist.all_reduce(half, op=dist.ReduceOp.SUM)
+        work.wait()
+        torch.cuda.current_stream().wait_stream(comm)
+        torch.cuda.synchronize()
+        ok = torch.equal(flat.cpu(), torch.arange(4096, dtype=torch.float32)) and torch.equal(half.float().cpu(), torch.arange(1024).float().to(torch.bfloat16).float())
+        out.put(("ok", (ok, dist.get_backend())))
+        dist.destroy_process_group()
+    except Exception as e:
+        out.put(("err", f"{type(e).__name__}: {e}"))
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_executes_the_exchange_calls_on_one_rank():
+    """The driver's multi-GPU run uses backend "nccl" (= RCCL).  A one-GPU box cannot host two RCCL ranks, but a
+    one-rank RCCL group executes the same calls - communicator creation, an asynchronous fp32 range all-reduce and a bf16
+    all-reduce on the side stream, stream joins - so that path is not first exercised on the 8-GPU node."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, out))
+    p.start()
+    status, val = out.get(timeout=240)
+    p.join(timeout=60)
+    assert status == "ok", val
+    assert val[0] and val[1] == "nccl"

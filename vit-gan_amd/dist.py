@@ -55,20 +55,33 @@ class GradSync:
         self.comm = torch.cuda.Stream(device=device) if self.overlap else None
         self._pending: List = []
 
-    def reduce_range(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+    def reduce_range(self, flat: torch.Tensor, lo: int, hi: int, compress: bool = False) -> None:
         """SUM all-reduce flat[lo:hi] across ranks.  With overlap the collective runs on the side stream
-        after everything already enqueued on the current stream (which produced those gradients)."""
+        after everything already enqueued on the current stream (which produced those gradients).
+        compress: exchange a bf16 copy (half the bytes on the xGMI links; the sum is formed in bf16 by the collective and
+        written back to the fp32 buffer) - used for the generator's 12.6 M-parameter mapping layer, whose gradient is
+        complete only at the very end of the step and cannot be hidden behind compute."""
         if self.world == 1 or hi <= lo:
             return
         view = flat[lo:hi]
         if not self.overlap:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            if compress:
+                half = view.to(torch.bfloat16)
+                dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+                view.copy_(half)
+            else:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             return
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ready)
-            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if compress:  # cast, exchange and write-back all on the communication stream, in order
+                half = view.to(torch.bfloat16)
+                dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+                view.copy_(half)
+            else:
+                self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> None:
         """Make the current stream wait for every all-reduce launched since the last wait()."""

@@ -41,7 +41,7 @@ class GanEngine:
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
-                 two_stream: bool = False):
+                 two_stream: bool = False, compress_mapping_grad: bool = True):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
         Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
         diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
@@ -53,6 +53,8 @@ class GanEngine:
         passes, training.py:182-194), then the generator's pass through D as two half-batches side by side.  Kernels of the
         two chains are in different phases (a GEMM main loop next to another GEMM's epilogue, a LayerNorm next to a
         GEMM), which the single-chain step cannot be: every launch of this model covers the chip about once.
+        compress_mapping_grad (data parallel only): exchange the gradient of the generator's mapping Linear - 50 MB of
+        the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).
         external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
         device inside the step - what parity tests use to give their CPU checker and the engine the same noise, also under
         hipGraph replay."""
@@ -73,7 +75,8 @@ class GanEngine:
         self.fuse = bool(fuse_real_fake)
         self.hyp = dict(lr_d=lr_d, lr_g=lr_g, wd=weight_decay, b1=betas[0], b2=betas[1], eps=eps)
         self.clip_d, self.clip_g = clip_d, clip_g
-        self.dp_chunks = 3  # pieces of the D backward whose gradient exchange overlaps the remaining backward
+        self.dp_chunks = 3  # pieces of the D / G backward whose gradient exchange overlaps the remaining backward
+        self.compress_map = bool(compress_mapping_grad)
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
@@ -160,6 +163,28 @@ class GanEngine:
         for s0, s1, lo, hi in backward_pieces(nL, self.dp_chunks, lay.layer0, lay.layer_stride, fd.total):
             _lib.check(L.vg_vit_backward_stages(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, s0, s1, st), "vg_vit_backward_stages")
             self.sync.reduce_range(fd.grad, lo, hi)
+
+    def _g_backward(self, ng, st) -> None:
+        """G backward; under data parallelism in ``dp_chunks`` pieces like D's: SIREN head + upper blocks first, their
+        gradients (a contiguous tail of the flat buffer) are exchanged while the lower blocks still run.  What is left
+        exposed is the front of the buffer - learned embedding, mapping Linear, lowest blocks - which only completes
+        with the last kernel; its 50 MB mapping-weight part goes over the links as bf16."""
+        L = _lib.lib()
+        fg = self.gen._flat
+        if self.world == 1:
+            _lib.check(L.vg_gen_backward(C.byref(ng), self.B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
+            return
+        lay = flat.gen_layout(self.gen._dims)
+        d = self.gen._dims
+        for s0, s1, lo, hi in backward_pieces(d.L, self.dp_chunks, lay.layer0, lay.layer_stride, fg.total):
+            _lib.check(L.vg_gen_backward_stages(C.byref(ng), self.B, _p(self.ws_g), _p(self.dfake), s0, s1, st), "vg_gen_backward_stages")
+            if lo == 0 and self.compress_map:  # [embedding | mapping weight | mapping bias, lowest blocks]
+                w0, w1 = lay.map_w, lay.map_w + d.T * d.E * d.Z
+                self.sync.reduce_range(fg.grad, 0, w0)
+                self.sync.reduce_range(fg.grad, w0, w1, compress=True)
+                self.sync.reduce_range(fg.grad, w1, hi)
+            else:
+                self.sync.reduce_range(fg.grad, lo, hi)
 
     def _adamw(self, fp, m, v, lr, st, clip=None, slot=0):
         h = self.hyp
@@ -290,8 +315,7 @@ class GanEngine:
             Dn = self.dfake[0].numel()
             _lib.check(L.vg_diversity_loss(fake_ptr, _p(self.dfake), _p(self.div_loss), _p(self.div_scratch), B, Dn, self.div_w, st),
                        "vg_diversity_loss")
-        _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
-        self.sync.reduce_range(fg.grad, 0, fg.total)
+        self._g_backward(ng, st)
         self.sync.wait()
         self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st, self.clip_g, 1)
 
