@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph; -1: auto (single GPU only)")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
+    ap.add_argument("--fp8-attention", type=int, default=-1,
+                    help="1: fp8 (e4m3) MFMA operands for the attention's Q.K^T and P.V; -1 (default): on for --workload c5 (BASELINE.json "
+                         "configs[4] names fp8 MFMA attention), off otherwise")
     ap.add_argument("--two-stream", type=int, default=0, help="1: run the step as two concurrent chains on two HIP streams (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
@@ -222,6 +225,8 @@ def main():
                  patch_size=geo["patch"], image_size=IMG, input_channels=3, classes_count=1,
                  dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
     D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
+    fp8_attn = (args.workload == "c5") if args.fp8_attention < 0 else bool(args.fp8_attention)
+    D.vit.attention_fp8 = fp8_attn
     if args.workload == "c2":
         G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
     else:
@@ -278,7 +283,8 @@ def main():
                                     "c4": "C4 shape: 3x64x64, patch 8 (65 tokens), E=512, 8 heads, 6 blocks ViT discriminator + patch-grid "
                                           "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW",
                                     "c5": "C5 shape: 3x128x128, patch 16 (65 tokens), E=768, 12 heads, 6 blocks ViT discriminator + patch-grid "
-                                          "SLN/SIREN generator (64 tokens), bf16 attention, full alternating G+D step, AdamW"}[args.workload],
+                                          "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW"}[args.workload],
+                       "fp8_attention": fp8_attn,
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
                        "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},

@@ -103,6 +103,14 @@ int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const 
 
 /* The same fused attention with the v1 discriminator's L2-distance scores (src/v1/attention.py:43-52,66-67, lp = 2):
  * out = softmax(cdist(q, k) * scale) @ v - the Euclidean distance itself, as the reference has it.  Same layouts. */
+/* The same fused attention with fp8 (OCP e4m3) MFMA operands for the activation products: Q.K^T in the forward and in the
+ * backward's recompute (so P agrees with the forward's lse) and P.V (numerators scaled by 256 into e4m3's normal range);
+ * the products with a gradient operand (dP, dV, dQ, dK) stay bf16.  Same layouts; outputs within ~2^-4 of the fp32 math. */
+int vg_attention_fp8_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE,
+                         float scale, void* stream);
+int vg_attention_fp8_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
+                         void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
+
 int vg_attention_l2_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE,
                         float scale, void* stream);
 int vg_attention_l2_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
@@ -193,6 +201,9 @@ typedef struct VgVitNet {
   const unsigned* dropout_step; /* optional device counter mixed into the mask key (hipGraph replay); NULL = none */
   void* ctx;                    /* optional vg_ctx_create() handle: the backward runs its weight-gradient side on the
                                    context's second stream, concurrently with the input-gradient chain; NULL = one stream */
+  int attn_fp8;                 /* 1: fp8 (OCP e4m3) MFMA operands for the attention's activation products, Q.K^T (forward
+                                   and the backward's recompute) and P.V, as BASELINE.json's 128x128 configuration asks;
+                                   gradient-carrying products stay bf16.  0 = bf16 everywhere (default; parity tiers) */
 } VgVitNet;
 /* img: [B,C,IH,IH] fp32 (img_is_bf16 = 0) or bf16; logits fp32 [B,Kc].  ws keeps everything the
  * backward needs; one ws per in-flight forward. */

@@ -283,3 +283,38 @@ def test_v2_vitgenerator_on_hip_matches_reference_fixture():
                 assert abs(float(s["norm"]) - ref_norm) < 2.0 ** -6 * ref_norm
                 scale = float(np.abs(npz[f"{tag}/out/sample"]).max())
                 assert float(np.abs(s["sample"] - npz[f"{tag}/out/sample"]).max()) < 2.0 ** -5 * scale
+
+
+def test_vit_with_fp8_attention_at_c5_geometry():
+    """BASELINE.json configs[4]: 128x128, patch 16, E=768, 12 heads with fp8 MFMA attention.  Whole network through the
+    module surface (``vit.attention_fp8 = True``) against the fp32 oracle: fp8 scores cost more than bf16 storage does -
+    2^-3 of max|ref| on logits and gradients (the operator itself is pinned tightly in test_ops_gpu.py::test_attention_fp8)."""
+    import gpu_util as u
+    from cases import VIT_CASES
+    from weights import make_input, make_state
+    from oracle import vit_oracle as vo
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.modules import ViTDiscriminator
+
+    c = VIT_CASES["c5"]
+    d = vo.VitDims(channels=3, image=128, patch=16, embed=768, heads=12, layers=c["layers"], mlp_ratio=2, classes=1)
+    st_np = make_state(vo.vit_param_shapes(d), c["seed"], "vit")
+    st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    x = torch.from_numpy(make_input((2, 3, 128, 128), c["seed"], "uniform"))
+    out = vo.vit_forward(st, x, d)
+    R = torch.from_numpy(make_input(tuple(out.shape), 3))
+    (out * R).sum().backward()
+    D = ViTDiscriminator(Config(embeddings_dimension=768, attention_heads_count=12, transformer_blocks_count=c["layers"], image_size=128,
+                                patch_size=16, classes_count=1, dropout_rate=0.0))
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in st_np.items()}, strict=True)
+    D = D.cuda().eval()
+    y_bf16 = D(x.cuda()).detach()
+    D.vit.attention_fp8 = True
+    y = D(x.cuda())
+    assert not torch.equal(y.detach(), y_bf16), "the flag must change the arithmetic"
+    u.assert_close(y, out, 2.0 ** -3, "logits (fp8 attention)")
+    D.zero_grad()
+    (y * R.cuda()).sum().backward()
+    got = dict(D.named_parameters())
+    for k in ("vit.encoder.0.attention.queries.weight", "vit.encoder.0.attention.values.weight", "vit.encoder.0.fc1.weight", "vit.embedding.conv1.weight"):
+        u.assert_close(got[k].grad, st[k].grad, 2.0 ** -3, f"grad {k} (fp8 attention)")

@@ -319,3 +319,54 @@ def test_linear_wgrad_rejects_undersized_slab_without_launching():
 def _lib_mod():
     from vit_gan_amd import _lib
     return _lib
+
+
+@pytest.mark.parametrize("B,H,S,HE", [(2, 12, 65, 64), (3, 4, 65, 96), (2, 4, 32, 96), (2, 4, 17, 32)])
+def test_attention_fp8(B, H, S, HE):
+    """fp8 (OCP e4m3) MFMA operands for Q.K^T and P.V (BASELINE.json configs[4]).  Two references: (a) the same math with
+    the operands quantised where the kernel quantises them (e4m3 Q, K for the scores in forward AND backward recompute;
+    e4m3 of 256 p and of V for P.V; every gradient-carrying product in bf16) - tight, it pins layout and scaling;
+    (b) plain fp32 attention - loose: what e4m3's 3 mantissa bits cost."""
+    u = _u()
+    E, scale = H * HE, 1 / math.sqrt(HE)
+    f8 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(B + H + S + HE)
+    qkv = u.rbf(torch.randn(B * S, 3 * E, generator=g) * 1.5)
+    dO = u.rbf(torch.randn(B * S, E, generator=g))
+    q, k, v = (qkv[:, i * E:(i + 1) * E].reshape(B, S, H, HE).transpose(1, 2) for i in range(3))
+    q8, k8, v8 = (t.to(f8).float() for t in (q, k, v))
+    s = (q8 @ k8.transpose(-1, -2)) * scale
+    m = s.max(-1, keepdim=True).values
+    p = torch.exp(s - m)
+    l = p.sum(-1, keepdim=True)
+    o = (((p * 256.0).to(f8).float() @ v8) / 256.0 / l)
+    lse_ref = (m + torch.log(l)).squeeze(-1)
+    o_rows = o.transpose(1, 2).reshape(B * S, E)
+    QKV = u.dev(qkv, u.BF)
+    O = torch.empty(B * S, E, dtype=u.BF, device="cuda")
+    LSE = torch.empty(B, H, S, device="cuda")
+    u.call("vg_attention_fp8_fwd", u.ptr(QKV), u.ptr(O), u.ptr(LSE), B, H, S, HE, scale, u.stream())
+    u.sync()
+    u.assert_close(LSE, lse_ref, 1e-4, "lse (fp8 scores)")
+    # e4m3 steps are 6-12 % apart: where 256 p sits at a rounding boundary (within the ~1e-3 by which the hardware's fp8 dot
+    # product and fp32 arithmetic on the quantised operands differ) one numerator moves a whole step, i.e. by up to
+    # 1/8 of a large probability - a few such elements per tensor reach 2 % of max|out|; the typical row is within 0.2 %
+    u.assert_close(O, o_rows, 2.0 ** -5, "attn out vs the e4m3-operand model")
+    assert float((O.float().cpu() - o_rows).abs().median()) < 2e-3 * float(o_rows.abs().max())
+    plain = (torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v).transpose(1, 2).reshape(B * S, E)
+    err = u.assert_close(O, plain, 2.0 ** -3, "attn out vs fp32 attention")
+    # backward: P from the fp8 scores and the forward's lse; gradient products in bf16 on the bf16 Q, K, V
+    Ost = O.float().cpu().reshape(B, S, H, HE).transpose(1, 2)
+    do = dO.reshape(B, S, H, HE).transpose(1, 2)
+    pn = torch.exp(s - lse_ref.unsqueeze(-1))
+    dp = do @ v.transpose(-1, -2)
+    delta = (do * Ost).sum(-1, keepdim=True)
+    ds = u.rbf(pn * (dp - delta) * scale)
+    ref = [ds @ k, ds.transpose(-1, -2) @ q, u.rbf(pn).transpose(-1, -2) @ do]
+    dQKV = torch.empty(B * S, 3 * E, dtype=u.BF, device="cuda")
+    DO = u.dev(dO, u.BF)
+    u.call("vg_attention_fp8_bwd", u.ptr(QKV), u.ptr(O), u.ptr(DO), u.ptr(LSE), u.ptr(dQKV), B, H, S, HE, scale, u.stream())
+    u.sync()
+    for i, nm in enumerate("qkv"):
+        u.assert_close(dQKV[:, i * E:(i + 1) * E], ref[i].transpose(1, 2).reshape(B * S, E), 2.0 ** -6, f"d{nm} vs the e4m3-operand model")
+    print(f"fp8 attention B={B} H={H} S={S} HE={HE}: forward within {err:.3f} of max|fp32 attention|")

@@ -30,7 +30,8 @@ class VgVitLayout(C.Structure):
 
 class VgVitNet(C.Structure):
     _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
-                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("ctx", c_void_p)]
+                ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("ctx", c_void_p),
+                ("attn_fp8", c_int)]
 
 
 class VgVitWsMap(C.Structure):
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "vg_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_unfold_tokens_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vg_unfold_tokens_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vg_attention_fp8_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_attention_fp8_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_l2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_l2_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -99,6 +99,33 @@ __device__ __forceinline__ bf16x8 lfrag_tr(const unsigned char* lds, int u, int 
   o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
   return o;
 }
+// ---- fp8 (OCP e4m3) operands for the activation-side products (config C5: "fp8 MFMA attention") ------------------------
+// An fp8 16x16x32 fragment is 8 bytes per lane, element j of lane group g pairing with element j of the other operand's
+// lane group g exactly like the bf16 fragment's 8 elements - so a bf16 fragment converts element by element.
+typedef long fp8x8;
+__device__ __forceinline__ fp8x8 to_fp8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(a4, a5, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(a6, a7, hi, true);
+  return (fp8x8)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+__device__ __forceinline__ fp8x8 to_fp8(bf16x8 v) {
+  return to_fp8(vg_bf2f(v[0]), vg_bf2f(v[1]), vg_bf2f(v[2]), vg_bf2f(v[3]), vg_bf2f(v[4]), vg_bf2f(v[5]), vg_bf2f(v[6]), vg_bf2f(v[7]));
+}
+__device__ __forceinline__ fp8x8 pack_pair_fp8(f32x4 a, f32x4 b, float mul) {  // same element order as pack_pair
+  return to_fp8(a[0] * mul, a[1] * mul, a[2] * mul, a[3] * mul, b[0] * mul, b[1] * mul, b[2] * mul, b[3] * mul);
+}
+__device__ __forceinline__ f32x4 vg_mfma_fp8(fp8x8 a, fp8x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+// score product with either operand type (FP8: both operands rounded to e4m3; accumulation stays fp32)
+template <bool FP8>
+__device__ __forceinline__ f32x4 score_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (FP8) return vg_mfma_fp8(to_fp8(a), to_fp8(b), c);
+  else return vg_mfma(a, b, c);
+}
+#define VG_P_FP8_SCALE 256.0f  // softmax numerators in (0, 1] are scaled into e4m3's normal range before the P.V product
+
 __device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
   bf16x8 o;
 #pragma unroll
@@ -133,7 +160,7 @@ __device__ __forceinline__ void row_sqnorms(const unsigned char* img, float* out
 // v1 attention score (src/v1/attention.py:66-67): the Euclidean distance |q - k| from q.k and the squared norms
 __device__ __forceinline__ float l2_dist(float qk, float qn, float kn) { return sqrtf(fmaxf(qn + kn - 2.f * qk, 0.f)); }
 
-template <int HE, int NT, bool L2>
+template <int HE, int NT, bool L2, bool FP8>
 __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                               float* __restrict__ lse, int S, int H, float scale,
                                                               const void* __restrict__ zeros) {
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
   for (int kt = 0; kt < NT; ++kt) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a = vg_mfma(lfrag_row<HE>(kl, 16 * kt, ks, lane), qf[ks], a);
+    for (int ks = 0; ks < KS; ++ks) a = score_mfma<FP8>(lfrag_row<HE>(kl, 16 * kt, ks, lane), qf[ks], a);
     sc[kt] = a;
   }
   const int q = 16 * qt + li;
@@ -209,17 +236,26 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
 #pragma unroll
   for (int u = 0; u < KP; ++u) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 pf = pack_pair(sc[2 * u], (2 * u + 1 < NT) ? sc[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero);
+    const f32x4 hi = (2 * u + 1 < NT) ? sc[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero;
+    if constexpr (FP8) {
+      const fp8x8 pf = pack_pair_fp8(sc[2 * u], hi, VG_P_FP8_SCALE);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma(lfrag_tr<HE>(vl, u, 16 * dt, lane), pf, oa[dt]);
+      for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma_fp8(to_fp8(lfrag_tr<HE>(vl, u, 16 * dt, lane)), pf, oa[dt]);
+    } else {
+      const bf16x8 pf = pack_pair(sc[2 * u], hi);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) oa[dt] = vg_mfma(lfrag_tr<HE>(vl, u, 16 * dt, lane), pf, oa[dt]);
+    }
   }
-  store_tiles<DT>(o + ((size_t)b * S + (q < S ? q : 0)) * E + h * HE, oa, inv_l, g, q < S);
+  store_tiles<DT>(o + ((size_t)b * S + (q < S ? q : 0)) * E + h * HE, oa, FP8 ? inv_l * (1.0f / VG_P_FP8_SCALE) : inv_l, g, q < S);
 }
 
 // Backward.  Phase A works in the S^T orientation (lane = query) and yields dQ; phase B in the
 // S orientation (lane = key) and yields dK, dV.  Recomputing the 65x65 tile in both orientations
 // costs 2 x 75 extra MFMAs per head and removes every register transpose.
-template <int HE, int NT, bool L2>
+// FP8: the score product is recomputed with the forward's e4m3 operands (so P matches the forward's lse exactly); every
+// product that carries a gradient operand (dP, dV, dQ, dK) stays bf16 - gradients need the range.
+template <int HE, int NT, bool L2, bool FP8>
 __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, int S, int H, float scale,
@@ -292,7 +328,7 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       f32x4 st = zero, dpt = zero;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        st = vg_mfma(lfrag_row<HE>(lk, 16 * kt, ks, lane), qf[ks], st);
+        st = score_mfma<FP8>(lfrag_row<HE>(lk, 16 * kt, ks, lane), qf[ks], st);
         dpt = vg_mfma(lfrag_row<HE>(lv, 16 * kt, ks, lane), dof[ks], dpt);
       }
       f32x4 kn4 = zero;
@@ -345,7 +381,7 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
       f32x4 s = zero, dp = zero;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = vg_mfma(lfrag_row<HE>(lq, 16 * qt, ks, lane), kf[ks], s);
+        s = score_mfma<FP8>(lfrag_row<HE>(lq, 16 * qt, ks, lane), kf[ks], s);
         dp = vg_mfma(lfrag_row<HE>(ldo, 16 * qt, ks, lane), vf[ks], dp);
       }
       const f32x4 lq4 = *(const f32x4*)(ll + 16 * qt + 4 * g);
@@ -400,40 +436,46 @@ static const void* attn_zeros() {
   return zp;
 }
 
-template <int HE, int NT, bool L2>
+template <int HE, int NT, int MODE>  // MODE: 0 dot-product bf16, 1 L2-distance scores, 2 dot-product with fp8 activation products
 static int launch_fwd(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
-  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT, L2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
   return (int)hipGetLastError();
 }
-template <int HE, int NT, bool L2>
+template <int HE, int NT, int MODE>
 static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
                       int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
-  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, L2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
   return (int)hipGetLastError();
 }
 
 // Supported shapes: head dim 32, 64 or 96; S <= 32 (2 tiles) or S <= 80 (5 tiles).
-// l2 = 0: dot-product scores (src/v2/modules.py:142-155, v1 lp = 1); l2 = 1: Euclidean-distance scores (v1 lp = 2).
-#define VG_ATTN_DISPATCH(FN, ...)                                                                       \
-  do {                                                                                                  \
-    if (S < 1 || S > 80 || B < 1 || H < 1) return -2;                                                   \
-    const bool small = (S <= 32);                                                                       \
-    if (HE == 96) return l2 ? (small ? FN<96, 2, true>(__VA_ARGS__) : FN<96, 5, true>(__VA_ARGS__))      \
-                            : (small ? FN<96, 2, false>(__VA_ARGS__) : FN<96, 5, false>(__VA_ARGS__));   \
-    if (HE == 64) return l2 ? (small ? FN<64, 2, true>(__VA_ARGS__) : FN<64, 5, true>(__VA_ARGS__))      \
-                            : (small ? FN<64, 2, false>(__VA_ARGS__) : FN<64, 5, false>(__VA_ARGS__));   \
-    if (HE == 32) return l2 ? (small ? FN<32, 2, true>(__VA_ARGS__) : FN<32, 5, true>(__VA_ARGS__))      \
-                            : (small ? FN<32, 2, false>(__VA_ARGS__) : FN<32, 5, false>(__VA_ARGS__));   \
-    return -3;                                                                                          \
+// mode = 0: dot-product scores (src/v2/modules.py:142-155, v1 lp = 1); 1: Euclidean-distance scores (v1 lp = 2);
+// 2: dot-product scores with fp8 (e4m3) operands for Q.K^T (forward and recompute) and P.V (config C5).
+#define VG_ATTN_BY_NT(FN, HE_, MODE_, ...) return small ? FN<HE_, 2, MODE_>(__VA_ARGS__) : FN<HE_, 5, MODE_>(__VA_ARGS__)
+#define VG_ATTN_BY_MODE(FN, HE_, ...)                                  \
+  do {                                                                 \
+    if (mode == 0) { VG_ATTN_BY_NT(FN, HE_, 0, __VA_ARGS__); }         \
+    if (mode == 1) { VG_ATTN_BY_NT(FN, HE_, 1, __VA_ARGS__); }         \
+    VG_ATTN_BY_NT(FN, HE_, 2, __VA_ARGS__);                            \
   } while (0)
-int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, int l2, hipStream_t st) {
+#define VG_ATTN_DISPATCH(FN, ...)                                      \
+  do {                                                                 \
+    if (S < 1 || S > 80 || B < 1 || H < 1) return -2;                  \
+    if (mode < 0 || mode > 2) return -4;                               \
+    const bool small = (S <= 32);                                      \
+    if (HE == 96) VG_ATTN_BY_MODE(FN, 96, __VA_ARGS__);                \
+    if (HE == 64) VG_ATTN_BY_MODE(FN, 64, __VA_ARGS__);                \
+    if (HE == 32) VG_ATTN_BY_MODE(FN, 32, __VA_ARGS__);                \
+    return -3;                                                         \
+  } while (0)
+int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, int mode, hipStream_t st) {
   VG_ATTN_DISPATCH(launch_fwd, qkv, o, lse, B, H, S, scale, st);
 }
 int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
-                       int S, int HE, float scale, int l2, hipStream_t st) {
+                       int S, int HE, float scale, int mode, hipStream_t st) {
   VG_ATTN_DISPATCH(launch_bwd, qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
 }

@@ -95,6 +95,16 @@ extern "C" int vg_attention_bwd(const void* qkv, const void* out, const void* d_
   return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale, 0,
                             (hipStream_t)stream);
 }
+extern "C" int vg_attention_fp8_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !lse) return -1;
+  return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, 2, (hipStream_t)stream);
+}
+extern "C" int vg_attention_fp8_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* d_qkv, int B, int H,
+                                    int S, int HE, float scale, void* stream) {
+  if (!qkv || !out || !d_out || !lse || !d_qkv) return -1;
+  return vg_attn_bwd_launch((const bf16*)qkv, (const bf16*)out, (const bf16*)d_out, lse, (bf16*)d_qkv, B, H, S, HE, scale, 2,
+                            (hipStream_t)stream);
+}
 extern "C" int vg_attention_l2_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;
   return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, 1, (hipStream_t)stream);

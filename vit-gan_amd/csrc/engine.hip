@@ -313,7 +313,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
                             w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), 0, st));
+    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
     VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
                             w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
@@ -402,7 +402,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
                             drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), 0, st));
+    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     // LN1 backward writes dL/dX[l] (and its masked copy for the dropout it meets next) into the OTHER set, which the
     // weight-gradient side of block l+1 may still be reading: wait for it first

@@ -3,9 +3,9 @@
 #include "vg_common.h"
 #include "vg_gemm.h"
 
-int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, int l2, hipStream_t st);
+int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, int HE, float scale, int mode, hipStream_t st);  // mode 0 dot, 1 L2 scores, 2 fp8 operands
 int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
-                       int S, int HE, float scale, int l2, hipStream_t st);
+                       int S, int HE, float scale, int mode, hipStream_t st);
 
 int vg_ln_fwd_launch(const bf16* x, long long xs, const float* gamma, const float* beta, bf16* y, long long ys,
                      float* mean, float* rstd, int R, int E, float eps, hipStream_t st);

@@ -139,7 +139,7 @@ class GanEngine:
         step_ptr = self.step_t.data_ptr()
         mk = lambda i, g=None, ctx=True: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(),  # noqa: E731
                                                        (fd.grad if g is None else g).data_ptr(), self.p_d, self.seed * 8 + i, step_ptr,
-                                                       self.ctx if ctx else None)
+                                                       self.ctx if ctx else None, int(self.vit.attention_fp8))
         if self.two_stream:  # chains run side by side: no third stream inside a pass; the fake chain accumulates into grad2
             return (mk(0, ctx=False), mk(1, self.grad2, ctx=False), mk(2, ctx=False), mk(3, ctx=False)), self._gen_net(step_ptr)
         return (mk(0), mk(1), mk(2)), self._gen_net(step_ptr)

@@ -211,6 +211,10 @@ class VisionTransformer(nn.Module):
         self.classifier = Classifier(embed_dim, n_classes)
         self.apply(vit_init_weights)
         self._dropout_p = float(dropout)
+        # fp8 (e4m3) MFMA operands for the attention's Q.K^T and P.V (BASELINE.json's 128x128 configuration); off by default
+        # - the reference's arithmetic is fp32 and the parity tiers are stated for bf16 storage.  Not a Config field: set
+        # ``model.vit.attention_fp8 = True`` (GanEngine picks it up too).
+        self.attention_fp8 = False
         self._dims = flat.vit_dims_struct(n_channels, image_size, patch_size, embed_dim, n_attention_heads, n_layers,
                                           forward_mul, n_classes)
         lay = flat.vit_layout(self._dims)  # raises for shapes the kernels do not cover
@@ -236,7 +240,7 @@ class VisionTransformer(nn.Module):
     def _net(self, need_grad: bool, drop=(0.0, 0)) -> _lib.VgVitNet:
         fp = self._flat
         return _lib.VgVitNet(self._dims, fp.flat.data_ptr(), fp.shadow.data_ptr(), fp.grad.data_ptr() if need_grad else None,
-                             float(drop[0]), int(drop[1]), None, _lib.context() if need_grad else None)
+                             float(drop[0]), int(drop[1]), None, _lib.context() if need_grad else None, int(self.attention_fp8))
 
     # -- forward -----------------------------------------------------------------------------
     def forward(self, x):
