@@ -124,6 +124,28 @@ int vg_unfold_tokens_fwd(const void* img, int img_is_bf16, void* tokens, int B, 
 int vg_unfold_tokens_bwd(const void* d_tokens, void* d_img, int B, int C, int IH, int P, int overlap,
                          void* stream);
 
+/* ---- second-order operators: the backward OF the backward operators --------------------------------------------------
+ * The gradient penalty of the reference's Wasserstein step (src/v2/utils.py:124-144, called at training.py:101-106)
+ * differentiates ||d D(x)/d x|| with respect to D's parameters: every backward operator on the input-gradient path needs a
+ * backward of its own.  For nn.Linear that is the GEMM family again (backward of dX = dY W:  d(dY) = ddX W^T = vg_linear_fwd,
+ * dW = dY^T ddX = vg_linear_wgrad); the three below are the non-linear ones.  u = dL/d(output of the backward operator). */
+/* elementwise activation on a stored bf16 pre-activation h (act 1 = GELU(erf), nn.GELU of modules.py:174; 3 = tanh, :191):
+ * fwd y = f(h); bwd dh = dy f'(h); bwd_bwd: d_dy = u f'(h), d_h = u dy f''(h).  n % 4 == 0. */
+int vg_act_fwd(const void* h, void* y, long long n, int act, void* stream);
+int vg_act_bwd(const void* dy, const void* h, void* dh, long long n, int act, void* stream);
+int vg_act_bwd_bwd(const void* u, const void* dy, const void* h, void* d_dy, void* d_h, long long n, int act,
+                   void* stream);
+/* backward of vg_layernorm_bwd (without residual): given u = dL/d(dx), writes d_dy = dL/d(dy) and d_x = dL/d(x) (bf16
+ * [R,E]) and per-workgroup partial sums of dL/d(gamma) (part: fp32 [vg_layernorm_bwd_bwd_parts(R)][E], fold with
+ * vg_colsum_f32).  E % 64 == 0, E <= 1024. */
+int vg_layernorm_bwd_bwd_parts(int R);
+int vg_layernorm_bwd_bwd(const void* u, const void* dy, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, void* d_dy, void* d_x, float* part, int R, int E, void* stream);
+/* backward of vg_attention_bwd: given u_qkv = dL/d(d_qkv) ([B*S, 3E], same layout as qkv), writes d_d_out = dL/d(d_out)
+ * [B*S, E] and d_qkv2 = dL/d(qkv) [B*S, 3E].  lse from the forward.  S <= 80 and 14 S HE + 16 S^2 + 8 S <= 160 KiB. */
+int vg_attention_bwd_bwd(const void* qkv, const void* d_out, const float* lse, const void* u_qkv, void* d_d_out,
+                         void* d_qkv2, int B, int H, int S, int HE, float scale, void* stream);
+
 /* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1;
  * kind 2 = the Wasserstein critic losses of src/v2/training.py:72,97).
  * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */

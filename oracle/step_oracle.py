@@ -60,6 +60,18 @@ def diversity_loss(fake: Tensor) -> Tensor:
     return torch.cdist(flat, flat, p=1).sum() / (B * (B - 1))
 
 
+def gradient_penalty(d_fn: Callable[[Tensor], Tensor], real: Tensor, fake: Tensor, epsilon: Tensor) -> Tensor:
+    """src/v2/utils.py:124-144: interpolate with a per-sample epsilon [B,1,1,1] (drawn by the caller: the reference draws
+    it with torch.rand inside), differentiate the discriminator's output sum w.r.t. the interpolated images with
+    create_graph=True, penalise (||grad||_2 - 1)^2 per sample, mean over the batch."""
+    x = (epsilon * real + (1 - epsilon) * fake).detach().requires_grad_(True)
+    out = d_fn(x)
+    (g,) = torch.autograd.grad(outputs=out, inputs=x, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True,
+                               only_inputs=True)
+    norm = g.reshape(g.shape[0], -1).norm(2, dim=1)
+    return ((norm - 1) ** 2).mean()
+
+
 class GanStepOracle:
     """Holds leaf tensors for D (v2 ViT) and G (v1 SLN/SIREN) and runs reference steps."""
 
@@ -73,6 +85,7 @@ class GanStepOracle:
         self.faithful = bool(faithful)
         self.clip_d, self.clip_g = clip_d, clip_g  # utils.clip_grad_norm_ max norms (training.py:78,104), None = off
         self.diversity_weight = 0.0                # weight of diversity_loss(fake) in the G loss (0.1 at training.py:73-74)
+        self.gp_weight = 0.0                       # c.lambda_gp of training.py:106 (the field is missing from the reference's Config)
         self.d = {k: v.detach().clone().float().requires_grad_(True) for k, v in d_state.items()}
         self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
         self.opt_d = torch.optim.AdamW(list(self.d.values()), lr=lr_d, weight_decay=weight_decay)
@@ -88,7 +101,7 @@ class GanStepOracle:
             return bf16_model.gen_forward(self.g, z, self.gdims, masks=masks)
         return gen_forward(self.g, z, self.gdims, masks=masks)
 
-    def step(self, real: Tensor, z: Tensor, noisy_inputs=None, masks=None) -> Dict[str, float]:
+    def step(self, real: Tensor, z: Tensor, noisy_inputs=None, masks=None, gp_epsilon: Tensor = None) -> Dict[str, float]:
         """noisy_inputs: optional (noisy_real, noisy_fake) the discriminator sees in ITS step (training.py:83-90:
         real / fake + 0.1 randn); the generator's pass through D always uses the clean fake.
         masks (test hook): explicit dropout multipliers standing in for nn.Dropout's RNG, a dict with the keys "d_real",
@@ -101,6 +114,13 @@ class GanStepOracle:
         fake = self.G(z, mk.get("g"))
         loss_fake = d_loss_fake(self.D(fake.detach() if noisy_inputs is None else noisy_inputs[1], mk.get("d_fake")), self.loss)
         loss_fake.backward()
+        self.last_gp = None
+        if self.gp_weight:  # loss += c.lambda_gp * gradient_penalty(D, noisy_real, noisy_fake), training.py:101-106 (fp32 path)
+            r_in = real if noisy_inputs is None else noisy_inputs[0]
+            f_in = fake.detach() if noisy_inputs is None else noisy_inputs[1]
+            gp = gradient_penalty(lambda t: vit_forward(self.d, t, self.ddims), r_in, f_in, gp_epsilon)
+            (self.gp_weight * gp).backward()
+            self.last_gp = float(gp.detach())
         if self.clip_d is not None:
             torch.nn.utils.clip_grad_norm_(list(self.d.values()), max_norm=self.clip_d)
         self.opt_d.step()

@@ -219,8 +219,49 @@ def v1tokens_case():
     print("v1tokens:", {k: rec[k].shape for k in rec if k.endswith("tokens")})
 
 
+GP_CASE = dict(image=32, patch=4, embed=128, heads=4, layers=2, mlp_ratio=2, classes=1, channels=3, batch=3, seed=41, eps_seed=5)
+
+
+def gp_case(v2m, v2u, only: bool = False):
+    """The reference's ``gradient_penalty`` (src/v2/utils.py:124-144) on its own ViTDiscriminator: the
+    penalty value, d penalty / d theta for every parameter, and the epsilon it drew (replayed from the seed)."""
+    c = GP_CASE
+    cfg = v2u.Config(attention_heads_count=c["heads"], batch_size=c["batch"], classes_count=c["classes"], dropout_rate=0.0,
+                     embeddings_dimension=c["embed"], image_size=c["image"], input_channels=c["channels"], mlp_ratio=c["mlp_ratio"],
+                     patch_size=c["patch"], transformer_blocks_count=c["layers"])
+    D = v2m.ViTDiscriminator(cfg)
+    shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    st = make_state(shapes, c["seed"], "vit")
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    D.train()
+    real = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"], "uniform"))
+    fake = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"] + 1, "uniform"))
+    torch.manual_seed(c["eps_seed"])
+    eps = torch.rand(c["batch"], 1, 1, 1)          # what gradient_penalty draws first (utils.py:126)
+    torch.manual_seed(c["eps_seed"])
+    pen = v2u.gradient_penalty(D, real, fake, torch.device("cpu"))
+    pen.backward()
+    rec = {"torch_version": np.asarray(torch.__version__), "param_names": np.asarray(list(shapes.keys())), "epsilon": eps.numpy(),
+           "penalty": np.asarray(float(pen.detach()), dtype=np.float64)}
+    untouched = []
+    for k, p in D.named_parameters():
+        if p.grad is None:   # the input gradient does not depend on it at all (the output bias)
+            untouched.append(k)
+            continue
+        flat(f"grad/{k}", summarize(p.grad.numpy()), rec)
+    rec["no_grad"] = np.asarray(untouched)
+    for k in ("vit.norm.weight", "vit.encoder.0.norm1.bias", "vit.classifier.fc2.weight", "vit.encoder.1.attention.keys.bias"):
+        rec[f"full/{k}"] = dict(D.named_parameters())[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "gp_v2.npz"), **rec)
+    print(f"gp_v2: penalty {float(pen):.6f}  eps {eps.reshape(-1).tolist()}")
+
+
 def main():
     v2m, v2u, v1g = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "gp":
+        gp_case(v2m, v2u)
+        return
+    gp_case(v2m, v2u)
     v1tokens_case()
     for name, c in V1ATT_CASES.items():
         v1att_case(name, c)

@@ -1,0 +1,170 @@
+"""Gradient penalty (src/v2/utils.py:124-144, training.py:101-106) on the HIP path.
+
+(1) every twice-differentiable operator of vit_gan_amd.ops2 against torch's own double backward of the same operator:
+    first derivative taken with create_graph=True, contracted with a second random tensor, differentiated again;
+(2) the product ``gradient_penalty`` on the reference's golden case (tests/golden/gp_v2.npz: produced by the reference's
+    gradient_penalty on the reference's ViTDiscriminator) - penalty value and d penalty / d theta;
+(3) the engine step with the penalty against the step oracle.
+Tolerances: bf16 storage (2^-7 of max|ref| per rounding); second derivatives pass through 2-3 stored bf16 tensors -> 2^-5."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _second_order(fn_hip, fn_ref, inputs, seed):
+    """inputs: list of (tensor, differentiate?) - first entry is x.  Returns per-input [first grads (of x), second grads]."""
+    import gpu_util as u
+    res = []
+    for dev, fn in (("cuda", fn_hip), ("cpu", fn_ref)):
+        ts = [t.detach().clone().to(dev).requires_grad_(True) for t in inputs]
+        y = fn(*ts)
+        g = torch.Generator().manual_seed(seed)
+        U = u.rbf(torch.randn(y.shape, generator=g)).to(dev)
+        V = u.rbf(torch.randn(ts[0].shape, generator=g)).to(dev)
+        (gx,) = torch.autograd.grad(y, ts[0], grad_outputs=U, create_graph=True)
+        (gx * V).sum().backward()
+        res.append((y.detach(), gx.detach(), [t.grad for t in ts]))
+    return res
+
+
+def _compare(res, names, tol1=2.0 ** -6, tol2=2.0 ** -5):
+    import gpu_util as u
+    (y, gx, gg), (yr, gxr, ggr) = res
+    u.assert_close(y, yr, 2.0 ** -7, "forward")
+    u.assert_close(gx, gxr, tol1, "first derivative")
+    for n, a, b in zip(names, gg, ggr):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        u.assert_close(a, b, tol2, f"second-order gradient w.r.t. {n}", floor=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["gelu", "tanh"])
+def test_activation_double_backward(kind):
+    import gpu_util as u
+    from vit_gan_amd import ops2
+    h = u.rbf(torch.randn(130, 768, generator=torch.Generator().manual_seed(1)) * 1.5)
+    ref = (lambda t: F.gelu(t)) if kind == "gelu" else torch.tanh
+    _compare(_second_order(lambda t: ops2.act(t, kind), ref, [h], 2), ["h"])
+
+
+def test_linear_double_backward():
+    import gpu_util as u
+    from vit_gan_amd import ops2
+    g = torch.Generator().manual_seed(3)
+    x = u.rbf(torch.randn(195, 384, generator=g))
+    w = u.rbf(torch.randn(1152, 384, generator=g) / math.sqrt(384))
+    b = torch.randn(1152, generator=g) * 0.1
+    _compare(_second_order(lambda x_, w_, b_: ops2.linear(x_, w_, b_), lambda x_, w_, b_: F.linear(x_, w_, b_), [x, w, b], 4), ["x", "W", "b"])
+
+
+def test_layernorm_double_backward():
+    import gpu_util as u
+    from vit_gan_amd import ops2
+    g = torch.Generator().manual_seed(5)
+    x = u.rbf(torch.randn(130, 384, generator=g) * 1.3 + 0.2)
+    gam = 1 + 0.2 * torch.randn(384, generator=g)
+    bet = 0.1 * torch.randn(384, generator=g)
+    _compare(_second_order(lambda x_, g_, b_: ops2.layer_norm(x_, g_, b_), lambda x_, g_, b_: F.layer_norm(x_, (384,), g_, b_, 1e-5),
+                           [x, gam, bet], 6), ["x", "gamma", "beta"])
+
+
+@pytest.mark.parametrize("B,H,S,HE", [(2, 4, 65, 96), (2, 8, 65, 64), (3, 4, 17, 32)])
+def test_attention_double_backward(B, H, S, HE):
+    import gpu_util as u
+    from vit_gan_amd import ops2
+    E = H * HE
+    qkv = u.rbf(torch.randn(B, S, 3 * E, generator=torch.Generator().manual_seed(7)))
+
+    def ref(t):
+        q, k, v = (t[..., i * E:(i + 1) * E].reshape(B, S, H, HE).transpose(1, 2) for i in range(3))
+        p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(HE), -1)
+        return (p @ v).transpose(1, 2).reshape(B, S, E)
+    _compare(_second_order(lambda t: ops2.attention(t, H), ref, [qkv], 8), ["qkv"])
+
+
+def _golden_gp():
+    from make_golden import GP_CASE as c
+    from weights import make_input, make_state
+    from oracle import vit_oracle as vo
+    d = vo.VitDims(channels=c["channels"], image=c["image"], patch=c["patch"], embed=c["embed"], heads=c["heads"],
+                   layers=c["layers"], mlp_ratio=c["mlp_ratio"], classes=c["classes"])
+    st = make_state(vo.vit_param_shapes(d), c["seed"], "vit")
+    real = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"], "uniform"))
+    fake = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"] + 1, "uniform"))
+    return c, d, st, real, fake, np.load(os.path.join(GOLD, "gp_v2.npz"))
+
+
+def test_gradient_penalty_matches_the_reference_fixture():
+    import gpu_util as u
+    from oracle import step_oracle as so, vit_oracle as vo
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.modules import ViTDiscriminator
+    from vit_gan_amd.penalty import gradient_penalty
+    c, d, st_np, real, fake, npz = _golden_gp()
+    D = ViTDiscriminator(Config(attention_heads_count=c["heads"], classes_count=1, dropout_rate=0.0, embeddings_dimension=c["embed"],
+                                transformer_blocks_count=c["layers"], batch_size=c["batch"]))
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in st_np.items()}, strict=True)
+    D = D.cuda().train()
+    eps = torch.from_numpy(npz["epsilon"])
+    D.zero_grad()
+    pen = gradient_penalty(D, real.cuda(), fake.cuda(), epsilon=eps.cuda())
+    pen.backward()
+    torch.cuda.synchronize()
+    # oracle (fp32 CPU, pinned to the same fixture by tests/test_oracle_golden.py) for element-wise gradient comparison
+    st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
+    ref = so.gradient_penalty(lambda t: vo.vit_forward(st, t, d), real, fake, eps)
+    ref.backward()
+    print(f"penalty: HIP {float(pen):.6f}  reference {float(npz['penalty']):.6f}  oracle {float(ref):.6f}")
+    assert abs(float(pen) - float(npz["penalty"])) < 2.0 ** -6 * float(npz["penalty"]) + 1e-4
+    got = {"vit." + k if not k.startswith("vit.") else k: p.grad for k, p in D.named_parameters()}
+    worst = []
+    for k, p in st.items():
+        if p.grad is None:
+            continue
+        scale = float(p.grad.abs().max())
+        if scale < 1e-7:
+            continue
+        worst.append((u.assert_close(got[k], p.grad, 2.0 ** -4, f"d penalty / d {k}", floor=1e-5), k))
+    print("largest gradient deviations:", [(k, f"{v:.2e}") for v, k in sorted(worst, reverse=True)[:5]])
+    for k in ("vit.norm.weight", "vit.classifier.fc2.weight"):   # and directly against the reference's own numbers
+        u.assert_close(got[k], torch.from_numpy(npz[f"full/{k}"]), 2.0 ** -4, f"{k} vs the reference fixture", floor=1e-5)
+
+
+def test_engine_step_with_gradient_penalty():
+    """The reference's Wasserstein discriminator step with the penalty (training.py:83-106: critic loss + lambda_gp * gp,
+    clipping) through GanEngine vs the step oracle, same noise and the same epsilon."""
+    from vit_gan_amd.engine import GanEngine
+    from test_engine_gpu import _build
+    B = 8
+    D, G, oracle = _build(B, "wasserstein")
+    oracle.gp_weight = 10.0
+    oracle.clip_d = 5.0
+    eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True)
+    g = torch.Generator().manual_seed(0)
+    real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    z = torch.randn(B, 1024, generator=g)
+    eps = torch.rand(B, 1, 1, 1, generator=g)
+    eng.gp_epsilon = eps.cuda()
+    w0 = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    losses = eng.step(real.cuda(), z.cuda())
+    torch.cuda.synchronize()
+    # the oracle must see the engine's bf16 images (the penalty is evaluated on what D is fed)
+    ref = oracle.step(real.to(torch.bfloat16).float(), z, gp_epsilon=eps)
+    got = losses.cpu().tolist()
+    print(f"gp: engine {float(eng.gp_loss):.5f} oracle {oracle.last_gp:.5f}; losses {got} vs {ref}")
+    assert abs(float(eng.gp_loss) - oracle.last_gp) < 0.03 * abs(oracle.last_gp) + 1e-3
+    for x, k in zip(got, ("d_real", "d_fake", "g")):
+        assert abs(x - ref[k]) < 2e-2, (k, got, ref)
+    k = "vit.encoder.1.fc2.weight"
+    upd, ref_upd = D.state_dict()[k].detach().cpu() - w0[k], oracle.d[k].detach() - w0[k]
+    assert float((upd - ref_upd).abs().max()) < 1.1e-3 and float(((upd - ref_upd).abs() < 1e-4).float().mean()) > 0.9
+    with pytest.raises(ValueError):
+        GanEngine(D, G, batch=B, gp_weight=1.0, use_graph=True)

@@ -160,3 +160,29 @@ def test_v1_overlapping_tokeniser_oracle_matches_reference():
         B, C, IH, P, ov = (int(v) for v in npz[f"{tag}/geometry"])
         x = torch.from_numpy(make_input((B, C, IH, IH), 40 + B + IH, "uniform"))
         np.testing.assert_array_equal(ao.unfold_tokens(x, P, ov).numpy(), npz[f"{tag}/tokens"])
+
+
+def test_gradient_penalty_oracle_matches_reference():
+    """the reference's own ``gradient_penalty`` (src/v2/utils.py:124-144) run on its ViTDiscriminator
+    produced tests/golden/gp_v2.npz (penalty, the epsilon it drew, d penalty / d theta); the oracle's restatement on the
+    fp32 ViT oracle must reproduce all of it - the double backward through LayerNorm, softmax attention, GELU and tanh."""
+    from make_golden import GP_CASE as c
+    from oracle import step_oracle as so
+    npz = np.load(os.path.join(GOLD, "gp_v2.npz"))
+    d = vo.VitDims(channels=c["channels"], image=c["image"], patch=c["patch"], embed=c["embed"], heads=c["heads"],
+                   layers=c["layers"], mlp_ratio=c["mlp_ratio"], classes=c["classes"])
+    shapes = vo.vit_param_shapes(d)
+    assert list(shapes) == [str(s) for s in npz["param_names"]]
+    st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in make_state(shapes, c["seed"], "vit").items()}
+    real = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"], "uniform"))
+    fake = torch.from_numpy(make_input((c["batch"], c["channels"], c["image"], c["image"]), c["seed"] + 1, "uniform"))
+    pen = so.gradient_penalty(lambda t: vo.vit_forward(st, t, d), real, fake, torch.from_numpy(npz["epsilon"]))
+    np.testing.assert_allclose(float(pen), float(npz["penalty"]), rtol=2e-5)
+    pen.backward()
+    assert [str(s) for s in npz["no_grad"]] == [k for k, p in st.items() if p.grad is None] == ["vit.classifier.fc2.bias"]
+    for k, p in st.items():
+        if p.grad is not None:
+            _check_summary(npz, f"grad/{k}", p.grad.numpy(), rtol=1e-3)
+    for k in ("vit.norm.weight", "vit.encoder.0.norm1.bias", "vit.classifier.fc2.weight"):
+        ref = npz[f"full/{k}"]
+        np.testing.assert_allclose(st[k].grad.numpy(), ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()))

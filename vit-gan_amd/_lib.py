@@ -85,6 +85,12 @@ _SIGNATURES = {
     "vg_attention_fp8_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_l2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_l2_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_act_fwd": (c_int, [P, P, c_ll, c_int, P]),
+    "vg_act_bwd": (c_int, [P, P, P, c_ll, c_int, P]),
+    "vg_act_bwd_bwd": (c_int, [P, P, P, P, P, c_ll, c_int, P]),
+    "vg_layernorm_bwd_bwd_parts": (c_int, [c_int]),
+    "vg_layernorm_bwd_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "vg_attention_bwd_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "vg_diversity_loss": (c_int, [P, P, P, P, c_int, c_int, c_float, P]),

@@ -123,6 +123,31 @@ extern "C" int vg_unfold_tokens_bwd(const void* d_tokens, void* d_img, int B, in
   if (!d_tokens || !d_img || B < 1 || C < 1) return -1;
   return vg_unfold_tokens_bwd_launch((const bf16*)d_tokens, (bf16*)d_img, B, C, IH, P, overlap, (hipStream_t)stream);
 }
+extern "C" int vg_act_fwd(const void* h, void* y, long long n, int act, void* stream) {
+  if (!h || !y || n < 1) return -1;
+  return vg_act2_launch((const bf16*)h, nullptr, nullptr, (bf16*)y, nullptr, n, act, 0, (hipStream_t)stream);
+}
+extern "C" int vg_act_bwd(const void* dy, const void* h, void* dh, long long n, int act, void* stream) {
+  if (!dy || !h || !dh || n < 1) return -1;
+  return vg_act2_launch((const bf16*)h, (const bf16*)dy, nullptr, (bf16*)dh, nullptr, n, act, 1, (hipStream_t)stream);
+}
+extern "C" int vg_act_bwd_bwd(const void* u, const void* dy, const void* h, void* d_dy, void* d_h, long long n, int act, void* stream) {
+  if (!u || !dy || !h || !d_dy || !d_h || n < 1) return -1;
+  return vg_act2_launch((const bf16*)h, (const bf16*)dy, (const bf16*)u, (bf16*)d_dy, (bf16*)d_h, n, act, 2, (hipStream_t)stream);
+}
+extern "C" int vg_layernorm_bwd_bwd_parts(int R) { return vg_ln_bwd_bwd_nparts(R); }
+extern "C" int vg_layernorm_bwd_bwd(const void* u, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                    void* d_dy, void* d_x, float* part, int R, int E, void* stream) {
+  if (!u || !dy || !x || !mean || !rstd || !gamma || !d_dy || !d_x || !part) return -1;
+  return vg_ln_bwd_bwd_launch((const bf16*)u, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (bf16*)d_dy, (bf16*)d_x, part, R, E,
+                              (hipStream_t)stream);
+}
+extern "C" int vg_attention_bwd_bwd(const void* qkv, const void* d_out, const float* lse, const void* u_qkv, void* d_d_out, void* d_qkv2,
+                                    int B, int H, int S, int HE, float scale, void* stream) {
+  if (!qkv || !d_out || !lse || !u_qkv || !d_d_out || !d_qkv2) return -1;
+  return vg_attn_bwd_bwd_launch((const bf16*)qkv, (const bf16*)d_out, lse, (const bf16*)u_qkv, (bf16*)d_d_out, (bf16*)d_qkv2, B, H, S, HE,
+                                scale, (hipStream_t)stream);
+}
 extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role, float grad_scale,
                            void* stream) {
   if (!logits || !dlogits || !loss_out || n < 1) return -1;

@@ -57,6 +57,13 @@ int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, fl
     int _rc = (expr);           \
     if (_rc != 0) return _rc;   \
   } while (0)
+// second-order operators (second_order.hip): the backward of the backward operators, for the gradient penalty
+int vg_act2_launch(const bf16* h, const bf16* dy, const bf16* u, bf16* o0, bf16* o1, long long n, int mode, int what, hipStream_t st);
+int vg_ln_bwd_bwd_nparts(int R);
+int vg_ln_bwd_bwd_launch(const bf16* u, const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
+                         bf16* d_dy, bf16* d_x, float* part, int R, int E, hipStream_t st);
+int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
+                           int S, int HE, float scale, hipStream_t st);
 int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, float* scratch, hipStream_t st);
 int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st);
 int vg_diversity_launch(const bf16* x, bf16* d_img, float* loss_out, float* scratch, int B, int D, float weight, hipStream_t st);

@@ -41,7 +41,7 @@ class GanEngine:
                  concurrent_wgrad: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
-                 two_stream: bool = False, compress_mapping_grad: bool = True):
+                 two_stream: bool = False, compress_mapping_grad: bool = True, gp_weight: float = 0.0):
         """clip_d / clip_g: max gradient norms of ``clip_grad_norm_`` before each optimizer step (the reference's
         Wasserstein step uses 5.0 / 0.5, src/v2/training.py:78,104); None = no clipping (its live loop).
         diversity_weight: weight of ``diversity_loss(fake)`` in the generator loss (0.1 there, training.py:73-74; computed
@@ -53,6 +53,10 @@ class GanEngine:
         passes, training.py:182-194), then the generator's pass through D as two half-batches side by side.  Kernels of the
         two chains are in different phases (a GEMM main loop next to another GEMM's epilogue, a LayerNorm next to a
         GEMM), which the single-chain step cannot be: every launch of this model covers the chip about once.
+        gp_weight: weight of the WGAN-GP gradient penalty in the discriminator loss (``c.lambda_gp`` of training.py:106; the
+        field is missing from the reference's Config).  The penalty runs through torch autograd over the twice-
+        differentiable operator set (penalty.py) on the discriminator's real / fake inputs of this step and accumulates
+        into the same gradient buffer before the exchange and AdamW; not capturable in a hipGraph.
         compress_mapping_grad (data parallel only): exchange the gradient of the generator's mapping Linear - 50 MB of
         the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).
         external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
@@ -77,6 +81,11 @@ class GanEngine:
         self.clip_d, self.clip_g = clip_d, clip_g
         self.dp_chunks = 3  # pieces of the D / G backward whose gradient exchange overlaps the remaining backward
         self.compress_map = bool(compress_mapping_grad)
+        self.gp_w = float(gp_weight)
+        self.gp_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.gp_epsilon: Optional[torch.Tensor] = None  # tests: a fixed epsilon [B,1,1,1] instead of torch.rand
+        if self.gp_w != 0.0 and (use_graph or two_stream):
+            raise ValueError("gp_weight: the gradient penalty runs through torch autograd and cannot be captured / forked")
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
@@ -288,6 +297,13 @@ class GanEngine:
             torch.add(self.imgs.float(), self.inoise, alpha=self.inst_sigma, out=self.inoise)
             self.imgs_noisy.copy_(self.inoise)
             d_in = self.imgs_noisy
+        if self.gp_w != 0.0:  # gradient_penalty(D, noisy_real, noisy_fake) joins the D loss (training.py:101-106)
+            from .penalty import gradient_penalty
+            fd.attach_grads()
+            disc = self.vit
+            pen = gradient_penalty(disc, d_in[:B], d_in[B:], epsilon=self.gp_epsilon)
+            (self.gp_w * pen).backward()   # accumulates into the flat gradient buffer (the parameters' .grad are views of it)
+            self.gp_loss.copy_(pen.detach().reshape(1))
         if self.fuse:
             _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(d_in), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
             self._loss(0, B, 0, 0, st)

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, flat, ops
+from . import _lib, flat, ops, ops2
 from .config import GENERATOR_KINDS, Config
 from .flatparams import FlatParams
 from .generator import SirenGenerator
@@ -260,6 +260,36 @@ class VisionTransformer(nn.Module):
         # the classifier reads the CLS row only (:195), so normalising that row is equivalent to :236
         h = ops.layer_norm(h[:, :1, :], self.norm.weight, self.norm.bias, self.norm.eps)
         return self.classifier(h)
+
+
+    def twice_differentiable_forward(self, x):
+        """The same network through the twice-differentiable operator set (ops2.py): what ``gradient_penalty`` runs, since
+        it differentiates the input gradient (``torch.autograd.grad(..., create_graph=True)``, src/v2/utils.py:132-139).
+        Dropout, as in ``composed_forward``, is torch's own on the modules' nn.Dropout layers."""
+        if not x.is_cuda:
+            raise RuntimeError("VisionTransformer: the HIP engine needs cuda tensors; there is no CPU fallback")
+        emb = self.embedding
+        B, Cc, IH, IW = x.shape
+        P, E = emb.conv1.kernel_size[0], emb.conv1.out_channels
+        gh, gw = IH // P, IW // P
+        tiles = x.reshape(B, Cc, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cc * P * P)
+        tok = ops2.linear(tiles, emb.conv1.weight.reshape(E, -1), emb.conv1.bias) + emb.pos_embedding
+        h = emb.dropout(torch.cat((emb.cls_token.expand(B, 1, E).to(tok.dtype), tok), dim=1))
+        for blk in self.encoder:
+            a = blk.attention
+            n1 = ops2.layer_norm(h, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            w = torch.cat((a.queries.weight, a.keys.weight, a.values.weight), dim=0)
+            b = torch.cat((a.queries.bias, a.keys.bias, a.values.bias), dim=0)
+            ctx = ops2.attention(ops2.linear(n1, w, b), a.n_attention_heads, 1.0 / float(a.head_embed_dim) ** 0.5)
+            h = h + blk.dropout1(ops2.linear(ctx, a.out_projection.weight, a.out_projection.bias))
+            n2 = ops2.layer_norm(h, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            z = ops2.act(ops2.linear(n2, blk.fc1.weight, blk.fc1.bias), "gelu")
+            h = h + blk.dropout2(ops2.linear(z, blk.fc2.weight, blk.fc2.bias))
+        c = ops2.layer_norm(h[:, 0, :], self.norm.weight, self.norm.bias, self.norm.eps)   # only the CLS row reaches the classifier
+        t = ops2.act(ops2.linear(c, self.classifier.fc1.weight, self.classifier.fc1.bias), "tanh")
+        # Linear(E, classes_count): E multiply-adds per image and logit - the fused pass has a dedicated kernel for it; here
+        # it is left to torch so that it is twice differentiable without a kernel of its own
+        return torch.nn.functional.linear(t.float(), self.classifier.fc2.weight, self.classifier.fc2.bias)
 
 
 # --------------------------------------------------------------------------------------------

@@ -203,11 +203,11 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
                 loss: str = "ns", device: str = "cuda:0", seed: int = 0, data_loader: Optional[Iterable] = None,
                 fid_fn: Optional[Callable[[nn.Module, int], float]] = None, output_base: Optional[str] = None,
                 save_artifacts: bool = True, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
-                diversity_weight: float = 0.0, instance_noise: float = 0.0):
+                diversity_weight: float = 0.0, instance_noise: float = 0.0, gp_weight: float = 0.0):
     """``loss``: "ns" (default: the executable v1 loss), "hinge", or "wasserstein" - the critic losses of the reference's
     unreached step (training.py:67-125); ``clip_d`` / ``clip_g``: its clip_grad_norm_ limits (5.0 / 0.5 there);
     ``diversity_weight``: its diversity term (0.1 there); ``instance_noise``: sigma of the noise on D's inputs (0.1
-    there).  Its gradient penalty (double backward) is not built."""
+    there); ``gp_weight``: the weight of its gradient penalty (``c.lambda_gp``, a field the reference's Config lacks)."""
     global _log_file
     c = Config() if not config else Config(**config)
     if not torch.cuda.is_available():
@@ -222,7 +222,7 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
     D, G = gan.discriminator, gan.generator
     eng = GanEngine(D, G, batch=c.batch_size, loss=loss, lr_d=c.discriminator_learning_rate, lr_g=c.generator_learning_rate,
                     weight_decay=1e-3, seed=seed, clip_d=clip_d, clip_g=clip_g, diversity_weight=diversity_weight,
-                    instance_noise=instance_noise)
+                    instance_noise=instance_noise, gp_weight=gp_weight)
     loader = data_loader if data_loader is not None else SyntheticLoader(c, steps_per_epoch, dev)
     epochs = c.epochs if max_epochs is None else min(c.epochs, max_epochs)
 
