@@ -235,7 +235,6 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   }
   const int bid_first = wg * grp.tpw;
   const int bid_end = min(bid_first + grp.tpw, grp.total);
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: per-wave LDS bases stay in SGPRs
   const int wm = wid >> 1, wn = wid & 1;  // wm in [0, WM)
@@ -602,7 +601,9 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   // workgroup 6.80 ms/step; two tiles wherever the launch has >= 2 tiles per CU slot (the QKV forward) 6.86; two / three /
   // four everywhere 8.3 / 10.2 / 11.8 - the hardware's own refill of CU slots already staggers the workgroups of a
   // multi-round launch, and in the single-round launches of this model (390-780 tiles) fewer, longer workgroups only cost
-  // occupancy.  The product therefore runs one tile per workgroup; the seam is exercised by the tests through the tuning
+  // occupancy.  (Also measured and dropped: delaying the second workgroup of every CU by 1-6 us at the start so that the two
+  // are in different phases - 6.83 -> 6.83 / 6.87 / 6.91 / 6.98 ms with the delay - and running the step as two concurrent
+  // half-batch chains, engine.py two_stream: +2 %.)  The product therefore runs one tile per workgroup; the seam is exercised by the tests through the tuning
   // build (VG_GEMM_TPW) and is the hook for shapes with many rounds of tiles.
   int tpw = 1;
 #ifdef VG_TUNING
@@ -612,6 +613,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   }
 #endif
   grp.tpw = tpw;
+
   grp.total = total;
   dim3 grid((total + tpw - 1) / tpw);
   const int act = probs[0].act;
