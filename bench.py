@@ -171,6 +171,8 @@ def main():
                          "configs[4] names fp8 MFMA attention), off otherwise")
     ap.add_argument("--two-stream", type=int, default=0, help="1: run the step as two concurrent chains on two HIP streams (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="profiling aid: skip the dominant-kernel timing leg, so a rocprofv3 run of this command contains the step's launches only")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
     ap.add_argument("--roofline-only", action="store_true", help="profiling aid: run only the dominant-kernel timing leg and print its object")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -271,7 +273,8 @@ def main():
         f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
-        roof = gemm_roofline(torch, 256 if args.workload != "c2" else B)  # the roofline leg always times the C2 shape
+        # the roofline leg always times the C2 shape
+        roof = {"skipped": "--no-roofline"} if args.no_roofline else gemm_roofline(torch, 256 if args.workload != "c2" else B)
         roof["step_tflops_per_gpu"] = round(step_tf, 1)
         roof["step_frac_of_peak"] = round(step_tf / PEAK_BF16_TFLOPS, 4)
         out = {

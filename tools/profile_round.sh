@@ -10,16 +10,16 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() { d=$1; shift; rocprofv3 "$@" > $OUT/$d.log 2>&1; }
-prof ks_default --kernel-trace --stats --output-format csv -d $OUT/ks_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline
-prof ks_single  --kernel-trace --stats --output-format csv -d $OUT/ks_single  -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-stream
+prof ks_default --kernel-trace --stats --output-format csv -d $OUT/ks_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+prof ks_single  --kernel-trace --stats --output-format csv -d $OUT/ks_single  -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --single-stream
 prof ks_roof    --kernel-trace --stats --output-format csv -d $OUT/ks_roof    -- python3 $R/bench.py --roofline-only
 export REPS=3
 prof gf --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gemm_fetch -- python3 $R/tools/gemm_bench.py
 prof gw --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/gemm_write -- python3 $R/tools/gemm_bench.py
 unset REPS
-prof sm --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/step_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --single-stream
-prof sf --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/step_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --single-stream
-prof sw --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/step_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --single-stream
+prof sm --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/step_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --single-stream
+prof sf --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/step_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --single-stream
+prof sw --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/step_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --single-stream
 cd $R
 python3 tools/pmc_traffic.py $OUT/gemm_fetch $OUT/gemm_write $OUT/${TAG}_gemm_pmc_traffic.json > $OUT/traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/step_mfma $OUT/step_fetch $OUT/step_write $OUT/${TAG}_step_pmc_summary.json > $OUT/summary.txt 2>&1
