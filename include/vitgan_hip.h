@@ -44,7 +44,8 @@ int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* r
                   void* stream);
 /* input gradient of nn.Linear:  dX[M,K] = dY[M,N] @ W[N,K]   (autograd of F.linear)
  * mul_mode 0: none; 4: dX *= gelu'(Z) with Z bf16 [M,K]; 5: dX *= s*cos(s*Zf), Zf fp32 [M,K];
- * 6: dX *= 1 - Z^2 (Z = tanh output, bf16 [M,K]). */
+ * 6: dX *= 1 - Z^2 (Z = tanh output, bf16 [M,K]); 7: dX *= Z (Z = a derivative the forward stored, bf16 [M,K]:
+ * what the engine's fc2 input gradient uses with the gelu' its fc1 epilogue wrote). */
 int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode,
                     const void* Z, const float* Zf, float act_scale, void* stream);
 /* weight gradient of nn.Linear:  dW[N,K] (+)= dY[M,N]^T @ X[M,K], computed as `splits` slices of M

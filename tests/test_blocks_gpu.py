@@ -50,7 +50,8 @@ def _report(title, worst):
     assert not bad, f"{title}: beyond 2^-6 of max|ref|: {[(k, f'{v:.2e}') for k, v in bad[:12]]} ({len(bad)} tensors)"
 
 
-@pytest.mark.parametrize("case,B,dropout", [("c1", 3, 0.0), ("c1", 2, 0.1), ("c4", 2, 0.0)])
+# B = 32 (M = 2080 rows = 65 units of 32): the K = 384 Linears of that case run on the weights-in-registers kernel
+@pytest.mark.parametrize("case,B,dropout", [("c1", 3, 0.0), ("c1", 2, 0.1), ("c4", 2, 0.0), ("c1", 32, 0.1)])
 def test_vit_every_stage_against_the_model(case, B, dropout):
     import gpu_util as u
     from cases import VIT_CASES
@@ -150,7 +151,7 @@ def test_vit_every_stage_against_the_model(case, B, dropout):
     _report(f"ViT {case} B={B} p={dropout}", worst)
 
 
-@pytest.mark.parametrize("B,dropout,patch", [(3, 0.0, 0), (2, 0.2, 0), (2, 0.0, 4)])
+@pytest.mark.parametrize("B,dropout,patch", [(3, 0.0, 0), (2, 0.2, 0), (2, 0.0, 4), (32, 0.2, 0)])
 def test_generator_every_stage_against_the_model(B, dropout, patch):
     import gpu_util as u
     from weights import make_input, make_state

@@ -39,14 +39,15 @@ def test_mask_statistics_and_determinism():
     assert float((m > 0).float().mean(0).std()) < 0.02 and float((m > 0).float().mean(1).std()) < 0.03
 
 
-def test_vit_train_mode_matches_oracle_with_same_masks():
+@pytest.mark.parametrize("B", [3, 32])  # 32: M = 2080 rows, the K = 384 Linears (dropout + residual epilogue included) run on csrc/gemm_wr.hip
+def test_vit_train_mode_matches_oracle_with_same_masks(B):
     import gpu_util as u
     from cases import VIT_CASES
     from weights import make_input, make_state
     from oracle import vit_oracle as vo
     from vit_gan_amd import _lib, flat
 
-    c = dict(VIT_CASES["c1"]); B = 3
+    c = dict(VIT_CASES["c1"])
     d = vo.VitDims(layers=c["layers"], classes=1)
     st_np = make_state(vo.vit_param_shapes(d), c["seed"], "vit")
     x = torch.from_numpy(make_input((B, 3, 32, 32), c["seed"], "uniform"))

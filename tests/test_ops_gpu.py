@@ -50,6 +50,55 @@ def test_linear_fwd(M, N, K, act):
     u.assert_close(out, ref, BF_TOL, "out")
 
 
+# The K = 384 Linears with M % 32 == 0 and N % 128 == 0 run on the weights-in-registers kernel (csrc/gemm_wr.hip): rows are
+# dealt to the workgroups in units of 32, so the sizes below exercise runs of one short tile only (256 rows over 56-168
+# runs), full tiles followed by a 32/64/96-row tile, and the full-size launches of the C2 step.
+WR_SHAPES = [(256, 384), (1312, 1152), (4160, 768), (16640, 1152), (33280, 384), (33280, 768)]
+
+
+@pytest.mark.parametrize("M,N", WR_SHAPES)
+@pytest.mark.parametrize("res", [False, True])
+def test_linear_fwd_weights_in_registers(M, N, res):
+    u = _u()
+    K = 384
+    g = torch.Generator().manual_seed(M + 3 * N + int(res))
+    A = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    R = u.rbf(torch.randn(M, N, generator=g)) if res else None
+    ref = A @ W.t() + b + (R if res else 0.0)
+    dA, dW, db = u.dev(A, u.BF), u.dev(W, u.BF), u.dev(b)
+    dR = u.dev(R, u.BF) if res else None
+    out = torch.full((M + 64, N), 7.0, dtype=u.BF, device="cuda")  # guard rows: nothing may be written past M
+    u.call("vg_linear_fwd", u.ptr(dA), u.ptr(dW), u.ptr(db), u.ptr(dR) if res else None, u.ptr(out), None, None,
+           M, N, K, 0, 0.0, u.stream())
+    u.sync()
+    u.assert_close(out[:M], ref, BF_TOL, "out")
+    assert bool((out[M:] == 7.0).all()), "rows beyond M were written"
+
+
+@pytest.mark.parametrize("M,K", WR_SHAPES)
+@pytest.mark.parametrize("mul", [0, 7])
+def test_linear_dgrad_weights_in_registers(M, K, mul):
+    """dX[M, K] = dY[M, 384] @ W[384, K] (the out-proj / fc2 input gradients), optionally times a stored derivative."""
+    u = _u()
+    N = 384
+    g = torch.Generator().manual_seed(M + 5 * K + mul)
+    dY = u.rbf(torch.randn(M, N, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(N))
+    Z = u.rbf(torch.rand(M, K, generator=g) * 1.2 - 0.1)
+    ref = dY @ W
+    if mul == 7:
+        ref = ref * Z
+    out = torch.full((M + 64, K), 7.0, dtype=u.BF, device="cuda")
+    dZ, ddY, dW_ = u.dev(Z, u.BF), u.dev(dY, u.BF), u.dev(W, u.BF)
+    u.call("vg_linear_dgrad", u.ptr(ddY), u.ptr(dW_), u.ptr(out), M, N, K, mul, u.ptr(dZ) if mul else None, None,
+           0.0, u.stream())
+    u.sync()
+    u.assert_close(out[:M], ref, BF_TOL, "dX")
+    assert bool((out[M:] == 7.0).all()), "rows beyond M were written"
+
+
 @pytest.mark.parametrize("M,N,K", [(130, 384, 384), (260, 1152, 384), (192, 768, 96), (256, 48, 384), (100, 96, 768)])
 @pytest.mark.parametrize("mul", [0, 4, 5])
 def test_linear_dgrad(M, N, K, mul):

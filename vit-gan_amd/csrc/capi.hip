@@ -18,8 +18,8 @@ extern "C" int vg_linear_fwd(const void* A, const void* W, const float* bias, co
 extern "C" int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode, const void* Z,
                                const float* Zf, float act_scale, void* stream) {
   if (!dY || !W || !dX) return -1;
-  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS && mul_mode != VG_ACT_MUL_TANH_GRAD) return -4;
-  if (((mul_mode == VG_ACT_MUL_GELU_GRAD || mul_mode == VG_ACT_MUL_TANH_GRAD) && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
+  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS && mul_mode != VG_ACT_MUL_TANH_GRAD && mul_mode != VG_ACT_MUL_Z) return -4;
+  if (((mul_mode == VG_ACT_MUL_GELU_GRAD || mul_mode == VG_ACT_MUL_TANH_GRAD || mul_mode == VG_ACT_MUL_Z) && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
   VgGemmProb p = vg_gemm_prob();
   p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = K; p.K = N;
   p.C = (bf16*)dX; p.ldc = K; p.act = mul_mode; p.act_scale = act_scale;

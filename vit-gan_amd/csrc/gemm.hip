@@ -545,6 +545,20 @@ __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 
 
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return -1;
+  if (n == 1) {  // the K = 384 Linears go to the weights-in-registers kernel (gemm_wr.hip) when it covers them
+#if defined(VG_WR_OFF)  // A/B builds (make var DEFS=-DVG_WR_OFF): everything on the tiled kernel
+    constexpr int wr_on = 0;
+#elif defined(VG_TUNING)
+    static const int wr_on = getenv("VG_GEMM_WR") ? atoi(getenv("VG_GEMM_WR")) : 1;
+#else
+    constexpr int wr_on = 1;
+#endif
+    if (wr_on) {
+      const int r = vg_gemm_wr_try(probs[0], mode, stream);
+      if (r > 0) return 0;
+      if (r < 0) return -r;
+    }
+  }
   // tile height: 256 rows (8 waves) when every problem is tall enough to fill the chip that way
   // 256-row tiles (8 waves, 2 workgroups/CU) only when they still give every CU its two workgroups (>= 512 tiles)
   // and the epilogue is light; otherwise 128-row tiles (4 workgroups/CU): small problems (generator, M = 8192)

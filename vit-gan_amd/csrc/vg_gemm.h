@@ -60,5 +60,7 @@ struct VgGemmGroup {
 
 // Enqueue 1..VG_MAX_GROUP problems of one operand form as a single launch.
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream);
+// gemm_wr.hip: 1 = enqueued on the weights-in-registers kernel, 0 = problem not of its kind, < 0 = -hipError.
+int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream);
 // Convenience: zero-initialised problem.
 static inline VgGemmProb vg_gemm_prob() { VgGemmProb p = {}; p.splits = 1; return p; }
