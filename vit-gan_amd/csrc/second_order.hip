@@ -14,9 +14,9 @@
 // gelu'(h) = Phi(h) + h phi(h);  gelu''(h) = phi(h) (2 - h^2);  tanh' = 1 - t^2;  tanh'' = -2 t (1 - t^2)
 __device__ __forceinline__ void act_derivs(int mode, float h, float& f, float& d1, float& d2) {
   if (mode == 1) {
-    const float phi = 0.39894228040143268f * __expf(-0.5f * h * h);
-    const float ax = fabsf(h) * 0.70710678118654752f;
-    const float Phi = 0.5f * (1.0f + copysignf(vg_erf_pos(ax, __expf(-ax * ax)), h));
+    float Phi, e;
+    vg_phi_e(h, Phi, e);
+    const float phi = 0.39894228040143268f * e;
     f = h * Phi; d1 = Phi + h * phi; d2 = phi * (2.0f - h * h);
   } else {
     const float t = vg_tanh(h);

@@ -48,35 +48,38 @@ __device__ __forceinline__ float vg_wave_max(float v) {
   return v;
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below one bf16 ulp): one v_exp, one v_rcp,
-// a 5-term Horner chain - ~12 instructions instead of libm's branchy erff (keeps GEMM epilogues small).
-__device__ __forceinline__ float vg_erf_pos(float ax, float e /* = exp(-ax*ax) */) {
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+// Exact-erf GELU (nn.GELU default) and its derivative from ONE evaluation of Phi(x) = (1 + erf(x / sqrt 2)) / 2 and
+// e = exp(-x^2 / 2).  erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below one bf16 ulp): one v_exp, one v_rcp,
+// a 5-term Horner chain.  The GELU epilogue of the fc1 GEMM is VALU-bound, so the instruction count is the cost: the
+// reciprocal is the bare v_rcp_f32 (1 ulp; __frcp_rn expands to the 10-instruction IEEE division sequence), the exponential
+// the bare v_exp_f32 on -(k x)^2 with k^2 = log2(e) / 2, Phi one fma of the signed erf: 15 VALU instructions for both outputs.
+__device__ __forceinline__ void vg_phi_e(float x, float& phi, float& e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
+  const float y = x * 0.84932180028801907f;  // sqrt(log2(e) / 2)
+  e = __builtin_amdgcn_exp2f(-(y * y));      // exp(-x^2 / 2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  return 1.0f - poly * e;
+  const float er = copysignf(fmaf(-poly, e, 1.0f), x);  // erf(x / sqrt 2)
+  phi = fmaf(er, 0.5f, 0.5f);
 }
-__device__ __forceinline__ float vg_gelu(float x) {  // exact-erf GELU (nn.GELU default) to ~1e-7
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float e = __expf(-ax * ax);
-  const float er = copysignf(vg_erf_pos(ax, e), x);
-  return 0.5f * x * (1.0f + er);
+__device__ __forceinline__ float vg_gelu(float x) {
+  float phi, e;
+  vg_phi_e(x, phi, e);
+  return x * phi;
 }
-__device__ __forceinline__ float vg_gelu_grad(float x) {  // Phi(x) + x * phi(x); exp(-x^2/2) shared by both terms
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float e = __expf(-ax * ax);
-  const float er = copysignf(vg_erf_pos(ax, e), x);
-  return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
+__device__ __forceinline__ float vg_gelu_grad(float x) {  // Phi(x) + x * phi(x)
+  float phi, e;
+  vg_phi_e(x, phi, e);
+  return fmaf(x * 0.39894228040143268f, e, phi);
 }
-__device__ __forceinline__ void vg_gelu_both(float x, float& g, float& dg) {  // gelu(x) and gelu'(x) from one exp / rcp / Horner chain
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float e = __expf(-ax * ax);
-  const float phi = 0.5f * (1.0f + copysignf(vg_erf_pos(ax, e), x));
+__device__ __forceinline__ void vg_gelu_both(float x, float& g, float& dg) {
+  float phi, e;
+  vg_phi_e(x, phi, e);
   g = x * phi;
-  dg = phi + x * 0.39894228040143268f * e;
+  dg = fmaf(x * 0.39894228040143268f, e, phi);
 }
 __device__ __forceinline__ float vg_tanh(float x) {  // 1 - 2/(exp(2x)+1), saturates cleanly for |x| large
   const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 // Counter-based dropout: element e of a dropped tensor (row-major, linear index e) is kept iff byte (e & 3)
