@@ -72,6 +72,25 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
       __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[i]), (lptr_t)(smem + slot * WR_STAGE + 1024 * (wid + 4 * i)), 16, 0, 0);
   };
 
+  // ---- A addressing (its first two stages are issued together with the second round of the W load below) ----------
+  // per-lane DMA source offsets (bytes) of this wave's 4 pieces of a stage: piece p = wid + 4 i covers rows 8p .. 8p+7
+  unsigned voffA[4];
+  auto set_voff = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wid + 4 * i, r = 8 * p + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      voffA[i] = ((unsigned)min(r, eM - 1 - m0) * (unsigned)P.lda + (unsigned)c * 8u) * 2u;
+    }
+  };
+  const char* Ab = (const char*)P.A;
+  const long long row_bytes = (long long)P.lda * 2;
+  auto stage_src = [&](int m0, int ks) { return Ab + (long long)m0 * row_bytes + 128 * ks; };
+  const int m_begin = u0 * 32, nfull = (u1 - u0) >> 2, rem = (u1 - u0) & 3;
+  const int ntiles = nfull + (rem ? 1 : 0);
+  set_voff(m_begin);  // rows beyond M are clamped onto M - 1 (only the last tile of A can overhang)
+  auto issue_a01 = [&]() { issue4(stage_src(m_begin, 0), voffA, 2); issue4(stage_src(m_begin, 1), voffA, 3); };
+
   // ---- W -> registers, once, through LDS in full lines ------------------------------------------------------------
   bf16x8 wf[2][12];
   if (WTR == 0) {
@@ -90,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
       const int s0 = round ? 4 : 0, ns = round ? 2 : 4;
 #pragma unroll
       for (int s = 0; s < ns; ++s) issue4(wb + 128 * (s0 + s), voffW, s);
+      if (round == 1) issue_a01();  // slots 2, 3 are free in the second round: A's first stages ride on the same wait
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
       for (int s = 0; s < ns; ++s) {
@@ -136,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
         for (int i = 0; i < 2; ++i)
           __builtin_amdgcn_global_load_lds((gptr_t)(base + voffT[i]), (lptr_t)(smem + s * 8192 + 1024 * (wid + 4 * i)), 16, 0, 0);
       }
+      if (round == 1) issue_a01();  // the second round fills 32 KiB (slots 0, 1): A's first stages ride on the same wait
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
       for (int s = 0; s < ns; ++s) {
@@ -161,32 +182,13 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
   const bf16* const eres = NEED_Z ? P.Z : P.res; const int eldr = NEED_Z ? P.ldz : P.ldr;
   const unsigned dthr = P.drop_thresh, dkey = vg_drop_key(P.drop_key, P.drop_step); const float dscale = P.drop_scale;
 
-  // ---- A pipeline ----------------------------------------------------------------------------------------------------
-  // per-lane DMA source offsets (bytes) of this wave's 4 pieces of a stage: piece p = wid + 4 i covers rows 8p .. 8p+7
-  unsigned voffA[4];
-  auto set_voff = [&](int m0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = wid + 4 * i, r = 8 * p + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      voffA[i] = ((unsigned)min(r, eM - 1 - m0) * (unsigned)P.lda + (unsigned)c * 8u) * 2u;
-    }
-  };
-  const char* Ab = (const char*)P.A;
-  const long long row_bytes = (long long)P.lda * 2;
-  auto stage_src = [&](int m0, int ks) { return Ab + (long long)m0 * row_bytes + 128 * ks; };
-  const int m_begin = u0 * 32, nfull = (u1 - u0) >> 2, rem = (u1 - u0) & 3;
-  const int ntiles = nfull + (rem ? 1 : 0);
-  set_voff(m_begin);  // rows beyond M are clamped onto M - 1 (only the last tile of A can overhang)
-  issue4(stage_src(m_begin, 0), voffA, 0);
-  issue4(stage_src(m_begin, 1), voffA, 1);
-  issue4(stage_src(m_begin, 2), voffA, 2);
-  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  // ---- A pipeline: stages 0, 1 are in slots 2, 3 (landed with the W load), stage 2 goes to slot 0 now ---------------
+  issue4(stage_src(m_begin, 2), voffA, 0);
 
   u32x4 F[WR_NS];
   f32x4 acc[2][8];
   const unsigned fa1 = fa0 ^ 64u;
-  int base_slot = 0;  // slot of (tile, ks) = (base_slot + ks) & 3; six stages per tile
+  int base_slot = 2;  // slot of (tile, ks) = (base_slot + ks) & 3; six stages per tile
 
   // One tile of MT m-tiles (16 MT rows) at row m0.  `first`: no epilogue stores precede it; `has_next`: another tile
   // (its stages 0..2 are issued from here) follows at m0 + 128.
@@ -354,7 +356,7 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
   if (mode != VG_NT && mode != VG_NN) return 0;
   if (p.K != 384 || (p.N & 127) || p.M < 256 || (p.M & 31)) return 0;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return 0;
-  if (p.resf || p.row_in_per > 0 || p.pre_f32 || p.Cf || p.Zf || !p.C) return 0;
+  if (p.resf || p.row_in_per > 0 || p.pre_f32 || p.Cf || !p.C) return 0;
   if ((long long)(p.M + 128) * (long long)(p.N > p.ldc ? p.N : p.ldc) >= (1LL << 31)) return 0;
   if ((long long)p.M * p.lda * 2 >= (1LL << 32)) return 0;  // 32-bit lane offsets inside a tile only, but keep A itself addressable
   int feat = 0;
@@ -372,7 +374,6 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
   const dim3 grid(8 * 64), block(256);
 #define WR_LAUNCH(WTR_, ACT_, FEAT_) hipLaunchKernelGGL((vg_gemm_wr_kernel<WTR_, ACT_, FEAT_>), grid, block, 0, stream, a)
   if (mode == VG_NT) {
-    if (p.Z) return 0;
     if (p.act == VG_ACT_NONE) {
       if (feat == 0) WR_LAUNCH(0, VG_ACT_NONE, 0);
       else if (feat == WF_RES) WR_LAUNCH(0, VG_ACT_NONE, WF_RES);
@@ -383,7 +384,7 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
     }
   } else {
     if (feat != 0) return 0;
-    if (p.act == VG_ACT_NONE && !p.Z) WR_LAUNCH(1, VG_ACT_NONE, 0);
+    if (p.act == VG_ACT_NONE) WR_LAUNCH(1, VG_ACT_NONE, 0);  // Z / Zf are only read by the activations that name them
     else if (p.act == VG_ACT_MUL_Z && p.Z) WR_LAUNCH(1, VG_ACT_MUL_Z, 0);
     else return 0;
   }
