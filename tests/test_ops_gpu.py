@@ -56,6 +56,25 @@ def test_linear_fwd(M, N, K, act):
 WR_SHAPES = [(256, 384), (1312, 1152), (4160, 768), (16640, 1152), (33280, 384), (33280, 768)]
 
 
+@pytest.mark.parametrize("M,N", [(1312, 768), (16640, 768)])
+def test_linear_gelu_fwd_weights_in_registers(M, N):
+    """fc1: GELU epilogue with the bf16 pre-activation as second output."""
+    u = _u()
+    K = 384
+    g = torch.Generator().manual_seed(M + N)
+    A = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    pre = A @ W.t() + b
+    dA, dW, db = u.dev(A, u.BF), u.dev(W, u.BF), u.dev(b)
+    out = torch.empty(M, N, dtype=u.BF, device="cuda")
+    pre_b = torch.empty(M, N, dtype=u.BF, device="cuda")
+    u.call("vg_linear_fwd", u.ptr(dA), u.ptr(dW), u.ptr(db), None, u.ptr(out), u.ptr(pre_b), None, M, N, K, 1, 0.0, u.stream())
+    u.sync()
+    u.assert_close(pre_b, pre, BF_TOL, "pre_bf16")
+    u.assert_close(out, F.gelu(pre), BF_TOL, "gelu")
+
+
 @pytest.mark.parametrize("M,N", WR_SHAPES)
 @pytest.mark.parametrize("res", [False, True])
 def test_linear_fwd_weights_in_registers(M, N, res):

@@ -379,6 +379,8 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
       else if (feat == WF_RES) WR_LAUNCH(0, VG_ACT_NONE, WF_RES);
       else if (feat == (WF_RES | WF_DROP)) WR_LAUNCH(0, VG_ACT_NONE, WF_RES | WF_DROP);
       else return 0;
+    } else if (p.act == VG_ACT_GELU && feat == WF_C2) {
+      WR_LAUNCH(0, VG_ACT_GELU, WF_C2);
     } else {
       return 0;
     }
