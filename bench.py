@@ -173,7 +173,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="profiling aid: skip the dominant-kernel timing leg, so a rocprofv3 run of this command contains the step's launches only")
-    ap.add_argument("--single-stream", action="store_true", help="profiling aid: keep the weight-gradient side work on the main stream")
+    ap.add_argument("--single-stream", action="store_true", help="(default since round 2; kept for the profiling scripts) weight gradients on the main stream")
+    ap.add_argument("--concurrent-wgrad", type=int, default=0,
+                    help="1: the discriminator's weight gradients on a side stream beside its input gradients (the default until the "
+                         "persistent weights-in-registers GEMMs: their workgroups hold the CUs for a whole launch, and the side stream "
+                         "measured 6.70 vs 6.67 ms/step)")
     ap.add_argument("--roofline-only", action="store_true", help="profiling aid: run only the dominant-kernel timing leg and print its object")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the default and the measured path); gloo only to rehearse the multi-rank code path on a box "
@@ -236,7 +240,7 @@ def main():
                            dropout=0.2 if args.dropout else 0.0).to(dev).train()
     use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
-                    concurrent_wgrad=not args.single_stream, two_stream=bool(args.two_stream) and world == 1)
+                    concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream

@@ -142,8 +142,12 @@ def test_linear_dgrad(M, N, K, mul):
     u.assert_close(out, ref, BF_TOL, "dX")
 
 
+# rows % 32 == 0, N % 128 == 0, K % 384 == 0: the 128 x 384-tile kernel (csrc/gemm_tn.hip) - one, two and many stages per
+# K slice, ragged last slice (65 stages over 3 slices), K = 768 (two n-tiles); the other shapes stay on the tiled kernel
 @pytest.mark.parametrize("M,N,K,splits", [(1040, 384, 384, 4), (650, 1152, 384, 3), (512, 96, 768, 2), (2048, 384, 48, 8),
-                                          (256, 384, 384, 1), (130, 768, 384, 5)])
+                                          (256, 384, 384, 1), (130, 768, 384, 5),
+                                          (64, 384, 384, 2), (2080, 1152, 384, 3), (4160, 768, 384, 10), (2080, 384, 768, 5),
+                                          (33280, 1152, 384, 10)])
 def test_linear_wgrad(M, N, K, splits):
     u = _u()
     g = torch.Generator().manual_seed(M + N + K)

@@ -194,11 +194,22 @@ static int pick_splits(long long tiles, int Krows, int cap) {
   return (int)s;
 }
 static inline long long tiles128(long long m, long long n) { return ((m + 127) / 128) * ((n + 127) / 128); }
+// Blocks whose widths are multiples of 384 run their weight gradients on 128 x 384 tiles, one 8-wave workgroup per CU
+// (gemm_tn.hip): as many K slices as keep the grouped launch within one workgroup per CU.
+static inline bool wide_tiles(int E, int hidden) { return E % 384 == 0 && hidden % 384 == 0; }
+static inline long long tiles384(long long m, long long n) { return ((m + 127) / 128) * (n / 384); }
+static int pick_splits384(long long tiles, int Krows, int cap) {
+  long long s = 256 / tiles;
+  if (s > cap) s = cap;
+  if (s > Krows / 256) s = Krows / 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
 
 // =============================================================================================
 //                                   ViT (discriminator)
 // =============================================================================================
-#define VIT_SPLIT_CAP 8
+#define VIT_SPLIT_CAP 12
 #define EMB_SPLIT_CAP 32
 struct VitWs {
   bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *z1, *a1, *xcls, *hcls, *th;
@@ -422,6 +433,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
       // the slab and bslab carves hold VIT_SPLIT_CAP slices: never more (round 1 overran them from an environment knob)
       int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
+      if (wide_tiles(E, rE) && M % 32 == 0)
+        splits = pick_splits384(tiles384(3 * E, E) + tiles384(E, E) + tiles384(rE, E) + tiles384(E, rE), M, VIT_SPLIT_CAP);
 #ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
       static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
       if (split_env > 0 && split_env <= VIT_SPLIT_CAP) splits = split_env;
@@ -490,7 +503,7 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
 // =============================================================================================
 //                                   generator (v1 SLN / SIREN)
 // =============================================================================================
-#define GEN_SPLIT_CAP 8
+#define GEN_SPLIT_CAP 16
 struct GenWs {
   bf16 *zb, *wmod, *s1, *qkv, *cat, *htmp, *s2, *hout, *sf, *y1;
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf, *zf1, *zf2;
@@ -694,7 +707,8 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     {
       const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);
-      const int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
+      int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
+      if (wide_tiles(E, E) && R % 32 == 0) splits = pick_splits384(tiles384(3 * E, E) + 2 * tiles384(E, E), R, GEN_SPLIT_CAP);
       VgGemmProb pr[3];
       pr[0] = wg(w.dqkv, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);

@@ -545,6 +545,13 @@ __device__ __attribute__((aligned(16))) unsigned int vg_zero_page[4] = {0u, 0u, 
 
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return -1;
+#if !defined(VG_TN384_OFF)  // A/B builds (make var DEFS=-DVG_TN384_OFF): weight gradients on the tiled kernel
+  if (mode == VG_TN) {  // weight gradients whose n extent is a multiple of 384: 128 x 384 tiles (gemm_tn.hip)
+    const int r = vg_gemm_tn384_try(probs, n, stream);
+    if (r > 0) return 0;
+    if (r < 0) return -r;
+  }
+#endif
   if (n == 1) {  // the K = 384 Linears go to the weights-in-registers kernel (gemm_wr.hip) when it covers them
 #if defined(VG_WR_OFF)  // A/B builds (make var DEFS=-DVG_WR_OFF): everything on the tiled kernel
     constexpr int wr_on = 0;

@@ -62,5 +62,7 @@ struct VgGemmGroup {
 int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream);
 // gemm_wr.hip: 1 = enqueued on the weights-in-registers kernel, 0 = problem not of its kind, < 0 = -hipError.
 int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream);
+// gemm_tn.hip: grouped weight gradients on 128 x 384 tiles; same return convention, may lower probs[i].splits.
+int vg_gemm_tn384_try(VgGemmProb* probs, int n, hipStream_t stream);
 // Convenience: zero-initialised problem.
 static inline VgGemmProb vg_gemm_prob() { VgGemmProb p = {}; p.splits = 1; return p; }
