@@ -18,6 +18,7 @@ for path in sys.argv[1:]:
     h = C.CDLL(os.path.abspath(path))
     h.vg_linear_fwd.argtypes = [P] * 7 + [C.c_int] * 4 + [C.c_float, P]
     h.vg_linear_dgrad.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_float, P]
+    h.vg_linear_wgrad.argtypes = [P, P, P, P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]  # ABI >= 4
     libs.append((os.path.basename(path), h))
 st = P(torch.cuda.current_stream().cuda_stream)
 ROUNDS, REPS = int(os.environ.get("ROUNDS", "7")), int(os.environ.get("REPS", "20"))
@@ -61,3 +62,10 @@ for M in (33280, 16640):
         dy = torch.randn(M, N, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
         z = torch.randn(M, K, device="cuda").to(BF); dx = torch.empty(M, K, device="cuda", dtype=BF)
         bench(f"{nm} M={M}", [(n, (lambda h=h: h.vg_linear_dgrad(p(dy), p(w), p(dx), M, N, K, mul, p(z), None, 0.0, st))) for n, h in libs], 2.0 * M * N * K)
+    # weight gradients dW[N, K] = dY[M, N]^T X[M, K] (split-K slabs + the fold); WG_SPLITS K slices (default 10)
+    SPL = int(os.environ.get("WG_SPLITS", "10"))
+    for (N, K, nm) in [(1152, 384, "TN qkv wgrad"), (768, 384, "TN fc1 wgrad"), (384, 768, "TN fc2 wgrad"), (384, 384, "TN out wgrad")]:
+        dy = torch.randn(M, N, device="cuda").to(BF); x = torch.randn(M, K, device="cuda").to(BF)
+        dw = torch.empty(N, K, device="cuda"); slab = torch.empty(SPL * N * K, device="cuda")
+        bench(f"{nm} M={M}", [(n, (lambda h=h: h.vg_linear_wgrad(p(dy), p(x), p(dw), p(slab), slab.numel(), M, N, K, SPL, 0, st))) for n, h in libs],
+              2.0 * M * N * K)

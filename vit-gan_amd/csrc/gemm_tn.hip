@@ -10,6 +10,7 @@
 // barrier and the DMA issue.  Split-K slabs, the bias-gradient column sums (ones x dY fragments on the MFMA pipe) and the
 // grouped launch are those of the tiled kernel.
 #include "vg_gemm.h"
+#include <stdlib.h>
 
 namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -59,15 +60,18 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   const char* baseA = (const char*)(P.A + (size_t)k_begin * P.lda);
   const char* baseB = (const char*)(P.B + (size_t)k_begin * P.ldb);
   const long long stepA = (long long)32 * P.lda * 2, stepB = (long long)32 * P.ldb * 2;
-  auto issue = [&](int slot) {  // stages are issued strictly in order: the bases run along
+  // piece i of a stage: 0 = the dY image, 1..3 = the X images; stages are issued strictly in order, the bases run along
+  auto issue_piece = [&](int slot, int i) {
     asm volatile("" : "+s"(baseA), "+s"(baseB));
-    unsigned char* dst = smem + slot * TN_STAGE + 1024 * wid;
-    __builtin_amdgcn_global_load_lds((gptr_t)(baseA + offA), (lptr_t)dst, 16, 0, 0);
+    unsigned char* dst = smem + slot * TN_STAGE + 1024 * wid + 8192 * i;
+    if (i == 0) __builtin_amdgcn_global_load_lds((gptr_t)(baseA + offA), (lptr_t)dst, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)(baseB + offB + 256 * (i - 1)), (lptr_t)dst, 16, 0, 0);
+  };
+  auto advance = [&]() { baseA += stepA; baseB += stepB; };
+  auto issue = [&](int slot) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
-      __builtin_amdgcn_global_load_lds((gptr_t)(baseB + offB + 256 * b), (lptr_t)(dst + 8192 * (1 + b)), 16, 0, 0);
-    baseA += stepA;
-    baseB += stepB;
+    for (int i = 0; i < 4; ++i) issue_piece(slot, i);
+    advance();
   };
 
   // fragment addresses inside a stage (tr form: gemm.hip FragAddr<true>); second half of a fragment at + 1024
@@ -137,29 +141,55 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
 
   // One stage: B(s) (stage s+1 landed, nobody reads stage s-1), DMA of stage s+3 into the slot stage s-1 left, the
   // fragment reads of stage s+1 into the other register set, then this stage's MFMAs.
+#ifdef VG_TN_STAMPS  // diagnostic build (make var SRC=gemm_tn NAME=tnst DEFS=-DVG_TN_STAMPS, tools/tn_stamps.py): cycles per segment
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#define TSTAMP(i) do { const long long _n = (long long)__builtin_amdgcn_s_memtime(); tacc[i] += _n - tprev; tprev = _n; } while (0)
+  long long tprev = (long long)__builtin_amdgcn_s_memtime();
+  const long long tstart = tprev;
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
   auto stage = [&](Frags& cur, Frags& nxt, int s) {
     if (s + 1 < nsteps) {
       if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (s + 3 < nsteps) issue((s + 3) & 3);
-    wait_frags(cur);
-    if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 fm[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) fm[mt] = tn_frag(cur.al[mt], cur.ah[mt]);
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-      const bf16x8 fn = tn_frag(cur.bl[nt], cur.bh[nt]);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn, fm[mt], acc[nt][mt]);
+    TSTAMP(0);
+    // The two waves of a SIMD (w and w + 4) run the rest of the stage in OPPOSITE order: waves 0-3 issue their four DMA
+    // pieces and the 20 transposing fragment reads of stage s+1 first and multiply after, waves 4-7 multiply first.  Measured
+    // (in-kernel stamps, tools/tn_stamps.py; cycles per stage for 768 of MFMA on the SIMD): both waves in the same order
+    // 1670 - the pieces (~70 cycles each) and the reads (~16 each: the LDS queue takes one transposing read per ~4 cycles
+    // from the whole CU) ran with the MFMA pipe idle, then both waves' MFMAs queued on it; opposite order 1420; pieces and
+    // reads interleaved one by one behind the MFMAs 1590.  The reads are what is left: 0.83 per MFMA at this wave tile.
+    wait_frags(cur);  // requested a stage ago
+    if (wm == 0) {
+      if (s + 3 < nsteps) issue((s + 3) & 3);
+      if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
     }
-    if (do_cs) {
+    TSTAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      bf16x8 fm[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) accb[mt] = vg_mfma(ones, fm[mt], accb[mt]);
+      for (int mt = 0; mt < 4; ++mt) fm[mt] = tn_frag(cur.al[mt], cur.ah[mt]);
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        const bf16x8 fn = tn_frag(cur.bl[nt], cur.bh[nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn, fm[mt], acc[nt][mt]);
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) accb[mt] = vg_mfma(ones, fm[mt], accb[mt]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(2);
+    if (wm != 0) {
+      if (s + 3 < nsteps) issue((s + 3) & 3);
+      if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
+    }
+    TSTAMP(3);
   };
 #pragma unroll 1
   for (int s = 0; s < nsteps; s += 2) {
@@ -167,6 +197,12 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
     if (s + 1 < nsteps) stage(f1, f0, s + 1);
   }
 
+#ifdef VG_TN_STAMPS
+  if (grp.zeros && lane == 0) {
+    long long* o = (long long*)grp.zeros + ((size_t)bid * 8 + wid) * 8;
+    o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3]; o[4] = tprev - tstart; o[5] = nsteps;
+  }
+#endif
   // ---- epilogue: fp32 slab of this K slice (+ the column sums) --------------------------------------------------------
   const int g = lane >> 4, li = lane & 15;
   if (do_cs && g == 0) {
@@ -211,6 +247,9 @@ int vg_gemm_tn384_try(VgGemmProb* probs, int n, hipStream_t stream) {
   }
   VgGemmGroup grp;
   grp.n = n; grp.tpw = 1; grp.zeros = nullptr;
+#ifdef VG_TN_STAMPS
+  if (getenv("VG_STAMP_PTR")) grp.zeros = (const void*)strtoull(getenv("VG_STAMP_PTR"), nullptr, 16);
+#endif
   int total = 0;
   for (int i = 0; i < n; ++i) {
     VgGemmProb& p = probs[i];
