@@ -80,7 +80,7 @@ TRAFFIC_FILE = "profiles/r02_gemm_pmc_traffic.json"
 
 
 def gemm_roofline(torch, B):
-    """Dominant kernel of the step (rocprof: profiles/r02_bench_b256_single_stream_kernel_stats.csv) =
+    """Dominant kernel of the step (rocprof: profiles/r02_bench_b256_kernel_stats.csv) =
     vg_gemm_kernel<1, 4, 0, 0>, the input-gradient GEMM, timed at its heaviest shape, the QKV dgrad of the fused real+fake
     pass: dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.
 

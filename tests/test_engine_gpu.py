@@ -139,7 +139,7 @@ def _bench_like(B, seed=5, d_layers=2, g_layers=2, **kw):
     D = ViTDiscriminator(cfg).train()
     G = SirenGenerator(layers=g_layers, dropout=0.2).train()
     state = ({k: v.detach().clone() for k, v in D.state_dict().items()}, {k: v.detach().clone() for k, v in G.state_dict().items()})
-    opts = dict(batch=B, seed=77, external_noise=True, fuse_real_fake=True, concurrent_wgrad=True)
+    opts = dict(batch=B, seed=77, external_noise=True, fuse_real_fake=True, concurrent_wgrad=False)  # bench.py's defaults
     opts.update(kw)  # d_dropout / g_dropout = 0.0 switch the fused dropout off
     eng = GanEngine(D.cuda(), G.cuda(), **opts)
     return eng, D, G, state
@@ -160,18 +160,20 @@ def test_engine_graph_replay_equals_eager():
     """hipGraph replay (what bench.py times at N=1) against the eager enqueue of the same steps: every piece of training
     state - both master weight buffers, both bf16 shadows, all four AdamW moment buffers, the step counter - and the
     losses of all three steps must be BIT-equal (the kernels are deterministic; N calls of step() are N steps in both
-    modes).  The single-stream eager schedule must give the same bits as the two-stream one."""
+    modes).  The schedule with the weight gradients on a side stream (eager and captured) must give the same bits as the
+    single-stream one bench.py runs."""
     B, n = 4, 3
     runs = {}
     for name, kw in (("eager", dict(use_graph=False)), ("graph", dict(use_graph=True)),
-                     ("eager_1stream", dict(use_graph=False, concurrent_wgrad=False))):
+                     ("eager_side_stream", dict(use_graph=False, concurrent_wgrad=True)),
+                     ("graph_side_stream", dict(use_graph=True, concurrent_wgrad=True))):
         eng, D, G, _ = _bench_like(B, **kw)
         assert eng.p_d == 0.1 and eng.p_g == 0.2 and eng.fuse
         runs[name] = _run_steps(eng, n, B)
         assert eng.steps == n and int(eng.step_t) == n, (name, eng.steps, int(eng.step_t))
     ref_l, ref_s = runs["eager"]
     assert torch.isfinite(ref_l).all() and float(ref_s[0].abs().sum()) > 0
-    for name in ("graph", "eager_1stream"):
+    for name in ("graph", "eager_side_stream", "graph_side_stream"):
         l, s = runs[name]
         assert torch.equal(l, ref_l), (name, l, ref_l)
         for i, (a, b) in enumerate(zip(s, ref_s)):

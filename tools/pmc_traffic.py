@@ -24,7 +24,7 @@ SHAPES = [[M, 1152, 384], [M, 384, 384], [M, 768, 384], [M, 384, 768], [M, 768, 
 
 def per_shape(d, counter):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "vg_gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows = [r for r in csv.DictReader(open(f)) if "vg_gemm_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     per = len(rows) // len(NAMES)  # 3 warm-ups + REPS launches per shape, in gemm_bench.py's fixed order
     if per * len(NAMES) != len(rows):
