@@ -168,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
     }
     TSTAMP(1);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
     {
       bf16x8 fm[4];
 #pragma unroll
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
         for (int mt = 0; mt < 4; ++mt) accb[mt] = vg_mfma(ones, fm[mt], accb[mt]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(2);
     if (wm != 0) {

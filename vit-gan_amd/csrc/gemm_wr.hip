@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
 #pragma unroll
     for (int q = 0; q < LA; ++q)
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(F[q % WR_NS]) : "v"(frag_addr(q)), "n"(2048 * ((q % SPS) % MT)) : "memory");
+    __builtin_amdgcn_s_setprio(1);  // the MFMA stream outranks the co-resident workgroup's epilogue / DMA issue (step -0.3 %)
 #pragma unroll
     for (int ks = 0; ks < WR_KS; ++ks) {
       // B(g): my pieces of stage g+1 have landed (stage g+2's and, right after an epilogue, its stores may still fly);
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
       }
     }
     base_slot = (base_slot + WR_KS) & 3;
+    __builtin_amdgcn_s_setprio(0);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results, before the VALU reads them
 
     // ---- epilogue: a lane holds, per (n-tile, m-tile), 4 consecutive n of row li; v_permlane16_swap between the two n-tiles
