@@ -359,7 +359,12 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
   if (p.K != 384 || (p.N & 127) || p.M < 256 || (p.M & 31)) return 0;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return 0;
   if (p.resf || p.row_in_per > 0 || p.pre_f32 || p.Cf || !p.C) return 0;
-  if ((long long)(p.M + 128) * (long long)(p.N > p.ldc ? p.N : p.ldc) >= (1LL << 31)) return 0;
+  // 16-byte epilogue accesses at base + 32-bit element offsets, for every operand the epilogue touches
+  int ldmax = p.N > p.ldc ? p.N : p.ldc;
+  if (p.res) { if (p.ldr & 7) return 0; if (p.ldr > ldmax) ldmax = p.ldr; }
+  if (p.C2) { if (p.ldc2 & 7) return 0; if (p.ldc2 > ldmax) ldmax = p.ldc2; }
+  if (p.act == VG_ACT_MUL_Z) { if (!p.Z || (p.ldz & 7)) return 0; if (p.ldz > ldmax) ldmax = p.ldz; }
+  if ((long long)(p.M + 128) * (long long)ldmax >= (1LL << 31)) return 0;
   if ((long long)p.M * p.lda * 2 >= (1LL << 32)) return 0;  // 32-bit lane offsets inside a tile only, but keep A itself addressable
   int feat = 0;
   if (p.res) feat |= WF_RES;
