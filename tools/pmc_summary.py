@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MFMA utilisation per kernel and HBM traffic per step from rocprofv3 PMC passes (MI355X_MICROARCH.md conventions).
 
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d A -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --single-stream
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d A -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline   (the default schedule is single-stream)
   rocprofv3 --pmc FETCH_SIZE ... -d B -- (same command)        rocprofv3 --pmc WRITE_SIZE ... -d C -- (same command)
   python tools/pmc_summary.py A B C profiles/r01_step_pmc_summary.json
 
