@@ -45,7 +45,9 @@ def test_forward_and_input_gradient_repeatable(M, N, K):
         assert torch.equal(outs[i], outs[0]) and torch.equal(dxs[i], dxs[0]), f"launch {i} differs bitwise from launch 0"
 
 
-@pytest.mark.parametrize("M,N,K,splits", [(2080, 1152, 384, 3), (4160, 768, 1536, 5), (16640, 384, 768, 10), (96, 384, 384, 3)])
+# stages per K slice: 22/22/21, 26, 52, 1, 2, 3, 4 and 5 (the ring holds four: prologue-only, one refill, steady state)
+@pytest.mark.parametrize("M,N,K,splits", [(2080, 1152, 384, 3), (4160, 768, 1536, 5), (16640, 384, 768, 10), (96, 384, 384, 3),
+                                          (256, 384, 384, 4), (288, 128, 384, 3), (512, 256, 768, 4), (800, 384, 384, 5)])
 def test_weight_gradient_repeatable(M, N, K, splits):
     u = _u()
     g = torch.Generator().manual_seed(M + N + K + splits)
