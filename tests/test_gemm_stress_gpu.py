@@ -47,7 +47,8 @@ def test_forward_and_input_gradient_repeatable(M, N, K):
 
 # stages per K slice: 22/22/21, 26, 52, 1, 2, 3, 4 and 5 (the ring holds four: prologue-only, one refill, steady state)
 @pytest.mark.parametrize("M,N,K,splits", [(2080, 1152, 384, 3), (4160, 768, 1536, 5), (16640, 384, 768, 10), (96, 384, 384, 3),
-                                          (256, 384, 384, 4), (288, 128, 384, 3), (512, 256, 768, 4), (800, 384, 384, 5)])
+                                          (256, 384, 384, 4), (288, 128, 384, 3), (512, 256, 768, 4), (800, 384, 384, 5),
+                                          (4160, 512, 1024, 8)])  # last: the 128 x 512-tile variant
 def test_weight_gradient_repeatable(M, N, K, splits):
     u = _u()
     g = torch.Generator().manual_seed(M + N + K + splits)

@@ -147,7 +147,8 @@ def test_linear_dgrad(M, N, K, mul):
 @pytest.mark.parametrize("M,N,K,splits", [(1040, 384, 384, 4), (650, 1152, 384, 3), (512, 96, 768, 2), (2048, 384, 48, 8),
                                           (256, 384, 384, 1), (130, 768, 384, 5),
                                           (64, 384, 384, 2), (2080, 1152, 384, 3), (4160, 768, 384, 10), (2080, 384, 768, 5),
-                                          (33280, 1152, 384, 10)])
+                                          (33280, 1152, 384, 10),
+                                          (2080, 1536, 512, 4), (1040, 512, 1024, 8), (64, 128, 512, 1)])  # 128 x 512 tiles (E = 512)
 def test_linear_wgrad(M, N, K, splits):
     u = _u()
     g = torch.Generator().manual_seed(M + N + K)

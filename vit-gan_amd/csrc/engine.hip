@@ -196,8 +196,13 @@ static int pick_splits(long long tiles, int Krows, int cap) {
 static inline long long tiles128(long long m, long long n) { return ((m + 127) / 128) * ((n + 127) / 128); }
 // Blocks whose widths are multiples of 384 run their weight gradients on 128 x 384 tiles, one 8-wave workgroup per CU
 // (gemm_tn.hip): as many K slices as keep the grouped launch within one workgroup per CU.
-static inline bool wide_tiles(int E, int hidden) { return E % 384 == 0 && hidden % 384 == 0; }
-static inline long long tiles384(long long m, long long n) { return ((m + 127) / 128) * (n / 384); }
+// (tile width 384 when both widths are multiples of 384, else 512 when both are multiples of 512, else 0: tiled kernel)
+static inline int wide_bn(int E, int hidden) {
+  if (E % 384 == 0 && hidden % 384 == 0) return 384;
+  if (E % 512 == 0 && hidden % 512 == 0) return 512;
+  return 0;
+}
+static inline long long tiles_wide(long long m, long long n, int bn) { return ((m + 127) / 128) * (n / bn); }
 static int pick_splits384(long long tiles, int Krows, int cap) {
   long long s = 256 / tiles;
   if (s > cap) s = cap;
@@ -433,8 +438,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
       // the slab and bslab carves hold VIT_SPLIT_CAP slices: never more (round 1 overran them from an environment knob)
       int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
-      if (wide_tiles(E, rE) && M % 32 == 0)
-        splits = pick_splits384(tiles384(3 * E, E) + tiles384(E, E) + tiles384(rE, E) + tiles384(E, rE), M, VIT_SPLIT_CAP);
+      if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
+        splits = pick_splits384(tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn), M, VIT_SPLIT_CAP);
 #ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
       static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
       if (split_env > 0 && split_env <= VIT_SPLIT_CAP) splits = split_env;
@@ -708,7 +713,8 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     {
       const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);
       int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
-      if (wide_tiles(E, E) && R % 32 == 0) splits = pick_splits384(tiles384(3 * E, E) + 2 * tiles384(E, E), R, GEN_SPLIT_CAP);
+      if (const int bn = wide_bn(E, E); bn && R % 32 == 0 && E % 128 == 0)
+        splits = pick_splits384(tiles_wide(3 * E, E, bn) + 2 * tiles_wide(E, E, bn), R, GEN_SPLIT_CAP);
       VgGemmProb pr[3];
       pr[0] = wg(w.dqkv, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);

@@ -1,5 +1,6 @@
-// Weight-gradient GEMM with 128 x 384 output tiles:  dW[m, n] = sum_k dY[k, m] X[k, n]  (VG_TN, both operands k-major), for
-// the problems whose n extent is a multiple of the embedding width 384 - every Linear of the transformer blocks.  gfx950 only.
+// Weight-gradient GEMM with 128 x 384 (or 128 x 512) output tiles:  dW[m, n] = sum_k dY[k, m] X[k, n]  (VG_TN, both operands k-major), for
+// the problems whose n extent is a multiple of 384 (E = 384 / 768 models: every Linear of the transformer blocks) or of 512
+// (E = 512; template parameter NT = n-tiles per wave, 6 or 8).  gfx950 only.
 //
 // The tiled kernel of gemm.hip runs these with 128 x 128 tiles: 16 KiB of LDS-DMA per 64 MFMAs, and LDS-DMA issue slots
 // are what that kernel is short of.  Here a workgroup (8 waves as 2 (m) x 4 (n), each 64 x 96 = 4 x 6 MFMA
@@ -15,14 +16,18 @@
 namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-constexpr int TN_STAGE = 32768;  // [dY: 32 k x 128 m][X: 32 k x 3 x 128 n], 8 KiB each, tr form (gemm.hip)
 constexpr int TN_NSLOT = 4;
+// stage = [dY: 32 k x 128 m][X: 32 k x (BN / 128) x 128 n], 8 KiB each, tr form (gemm.hip): 32 KiB (NT = 6) or 40 KiB (NT = 8: the
+// ring is then all 160 KiB of the CU)
+template <int NT> constexpr int tn_stage() { return 8192 * (1 + NT / 2); }
 
 __device__ __forceinline__ int tn_sigma(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
 __device__ __forceinline__ bf16x8 tn_frag(u32x2 lo, u32x2 hi) { return __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]}); }
 }  // namespace
 
+template <int NT>
 __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup grp) {
+  constexpr int TN_STAGE = tn_stage<NT>(), BN = 64 * NT, NB = NT / 2, PPS = 1 + NB;  // X images, pieces per wave and stage
   __shared__ __attribute__((aligned(16))) unsigned char smem[TN_NSLOT * TN_STAGE];
   int bid;
   {  // XCD-aware block order (gemm.hip): each XCD takes a contiguous run of tiles - the tiles of one K slice share its rows
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   const int split = local / tiles_mn;
   const int rr = local - split * tiles_mn;
   const int tm = rr / P.tiles_n, tn = rr - tm * P.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 384;
+  const int m0 = tm * 128, n0 = tn * BN;
   const int k_begin = split * P.k_per_split, k_end = min(P.K, k_begin + P.k_per_split);
   const int nsteps = (k_end - k_begin) >> 5;
 
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   const char* baseA = (const char*)(P.A + (size_t)k_begin * P.lda);
   const char* baseB = (const char*)(P.B + (size_t)k_begin * P.ldb);
   const long long stepA = (long long)32 * P.lda * 2, stepB = (long long)32 * P.ldb * 2;
-  // piece i of a stage: 0 = the dY image, 1..3 = the X images; stages are issued strictly in order, the bases run along
+  // piece i of a stage: 0 = the dY image, 1..NB = the X images; stages are issued strictly in order, the bases run along
   auto issue_piece = [&](int slot, int i) {
     asm volatile("" : "+s"(baseA), "+s"(baseB));
     unsigned char* dst = smem + slot * TN_STAGE + 1024 * wid + 8192 * i;
@@ -70,50 +75,51 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   auto advance = [&]() { baseA += stepA; baseB += stepB; };
   auto issue = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(slot, i);
+    for (int i = 0; i < PPS; ++i) issue_piece(slot, i);
     advance();
   };
 
-  // fragment addresses inside a stage (tr form: gemm.hip FragAddr<true>); second half of a fragment at + 1024
-  unsigned adA[4], adB[6];
+  // fragment addresses inside a stage (tr form: gemm.hip FragAddr<true>); second half of a fragment at + 1024.  16 columns
+  // further on is chunk index + 2 BEFORE the XOR with the row's swizzle (an even number), i.e. address ^ (t << 5) as long as
+  // the fragments stay inside one 128-column image: true of the four dY fragments and, at NT = 8 (128 columns per wave), of
+  // the X fragments - one address register each instead of 4 + 8 (NT = 8 has none to spare: 128 accumulators, 96 fragment
+  // registers).  NT = 6 (96 columns per wave) crosses images and keeps its six X addresses.
+  unsigned adA0, adB[NT == 8 ? 1 : NT];
   {
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, sw = 2 * (q | ((g & 1) << 2)), kk0 = 8 * g + q;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int i0 = 64 * wm + 16 * mt, c8 = (i0 >> 2) + p;
-      adA[mt] = sbase + (unsigned)(kk0 * 256 + (((c8 >> 1) ^ sw) << 4) + ((c8 & 1) << 3));
+    {
+      const int c8 = ((64 * wm) >> 2) + p;
+      adA0 = sbase + (unsigned)(kk0 * 256 + (((c8 >> 1) ^ sw) << 4) + ((c8 & 1) << 3));
     }
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-      const int i0 = 96 * wn + 16 * nt, c8 = ((i0 & 127) >> 2) + p;
+    for (int nt = 0; nt < (NT == 8 ? 1 : NT); ++nt) {
+      const int i0 = 16 * NT * wn + 16 * nt, c8 = ((i0 & 127) >> 2) + p;
       adB[nt] = sbase + (unsigned)(8192 * (1 + (i0 >> 7)) + kk0 * 256 + (((c8 >> 1) ^ sw) << 4) + ((c8 & 1) << 3));
     }
   }
-  struct Frags { u32x2 al[4], ah[4], bl[6], bh[6]; };
+  struct Frags { u32x2 al[4], ah[4], bl[NT], bh[NT]; };
   auto read_frags = [&](Frags& f, int slot) {
-    const unsigned so = (unsigned)(slot * TN_STAGE);
+    const unsigned so = (unsigned)(slot * TN_STAGE);  // a multiple of 8 KiB: commutes with the XOR of bits 5-7
+    const unsigned a0 = adA0 + so;
     asm volatile(
         "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\tds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
         "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1024\n\tds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1024"
         : "=&v"(f.al[0]), "=&v"(f.ah[0]), "=&v"(f.al[1]), "=&v"(f.ah[1]), "=&v"(f.al[2]), "=&v"(f.ah[2]), "=&v"(f.al[3]), "=&v"(f.ah[3])
-        : "v"(adA[0] + so), "v"(adA[1] + so), "v"(adA[2] + so), "v"(adA[3] + so)
+        : "v"(a0), "v"(a0 ^ 32u), "v"(a0 ^ 64u), "v"(a0 ^ 96u)
         : "memory");
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %12 offset:1024\n\tds_read_b64_tr_b16 %2, %13\n\tds_read_b64_tr_b16 %3, %13 offset:1024\n\t"
-        "ds_read_b64_tr_b16 %4, %14\n\tds_read_b64_tr_b16 %5, %14 offset:1024\n\tds_read_b64_tr_b16 %6, %15\n\tds_read_b64_tr_b16 %7, %15 offset:1024\n\t"
-        "ds_read_b64_tr_b16 %8, %16\n\tds_read_b64_tr_b16 %9, %16 offset:1024\n\tds_read_b64_tr_b16 %10, %17\n\tds_read_b64_tr_b16 %11, %17 offset:1024"
-        : "=&v"(f.bl[0]), "=&v"(f.bh[0]), "=&v"(f.bl[1]), "=&v"(f.bh[1]), "=&v"(f.bl[2]), "=&v"(f.bh[2]), "=&v"(f.bl[3]), "=&v"(f.bh[3]),
-          "=&v"(f.bl[4]), "=&v"(f.bh[4]), "=&v"(f.bl[5]), "=&v"(f.bh[5])
-        : "v"(adB[0] + so), "v"(adB[1] + so), "v"(adB[2] + so), "v"(adB[3] + so), "v"(adB[4] + so), "v"(adB[5] + so)
-        : "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned ab = (NT == 8) ? ((adB[0] + so) ^ (unsigned)(nt << 5)) : (adB[NT == 8 ? 0 : nt] + so);
+      asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(f.bl[nt]), "=&v"(f.bh[nt]) : "v"(ab) : "memory");
+    }
   };
   auto wait_frags = [&](Frags& f) {  // the registers are tied to the wait, so no use of them can be scheduled above it
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f.al[0]), "+v"(f.ah[0]), "+v"(f.al[1]), "+v"(f.ah[1]), "+v"(f.al[2]), "+v"(f.ah[2]), "+v"(f.al[3]), "+v"(f.ah[3]),
-                   "+v"(f.bl[0]), "+v"(f.bh[0]), "+v"(f.bl[1]), "+v"(f.bh[1]), "+v"(f.bl[2]), "+v"(f.bh[2]), "+v"(f.bl[3]), "+v"(f.bh[3]),
-                   "+v"(f.bl[4]), "+v"(f.bh[4]), "+v"(f.bl[5]), "+v"(f.bh[5])
+                 : "+v"(f.al[0]), "+v"(f.ah[0]), "+v"(f.al[1]), "+v"(f.ah[1]), "+v"(f.al[2]), "+v"(f.ah[2]), "+v"(f.al[3]), "+v"(f.ah[3])
                  :
                  : "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(f.bl[nt]), "+v"(f.bh[nt])::"memory");  // behind the same wait
   };
 
   // bias-gradient column sums ride along (first n-tile, the wn == 0 waves): rows of ones x dY-fragment are all equal
@@ -121,11 +127,11 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
-  f32x4 accb[4], acc[6][4];
+  f32x4 accb[4], acc[NT][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   issue(0);
   if (nsteps > 1) issue(1);
   if (nsteps > 2) issue(2);
-  if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-  else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPS) : "memory");
+  else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   Frags f0, f1;
   read_frags(f0, 0);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
 #endif
   auto stage = [&](Frags& cur, Frags& nxt, int s) {
     if (s + 1 < nsteps) {
-      if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     TSTAMP(0);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) fm[mt] = tn_frag(cur.al[mt], cur.ah[mt]);
 #pragma unroll
-      for (int nt = 0; nt < 6; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         const bf16x8 fn = tn_frag(cur.bl[nt], cur.bh[nt]);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = vg_mfma(fn, fm[mt], acc[nt][mt]);
@@ -214,12 +220,12 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
   }
   float* const Cf = P.Cf + (size_t)split * P.cf_split_stride;
   const int ldcf = P.ldcf;
-  const int ncol = n0 + wn * 96 + ((g & 1) << 4) + ((g & 2) << 2);
+  const int ncol = n0 + wn * 16 * NT + ((g & 1) << 4) + ((g & 2) << 2);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + 16 * mt + li;
 #pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {
+    for (int pr = 0; pr < NT / 2; ++pr) {
       const f32x4 te = acc[2 * pr][mt], to = acc[2 * pr + 1][mt];
       f32x4 lo, hi;
 #pragma unroll
@@ -239,14 +245,19 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_tn384_kernel(const VgGemmGroup
 // May lower p.splits (empty slices are dropped), exactly like vg_gemm_launch.
 int vg_gemm_tn384_try(VgGemmProb* probs, int n, hipStream_t stream) {
   if (n < 1 || n > VG_MAX_GROUP) return 0;
+  bool w384 = true, w512 = true;
   for (int i = 0; i < n; ++i) {
     const VgGemmProb& p = probs[i];
-    if (p.M <= 0 || (p.M & 127) || p.N <= 0 || (p.N % 384) || p.K < 64 || (p.K & 31)) return 0;
+    if (p.M <= 0 || (p.M & 127) || p.N <= 0 || p.K < 64 || (p.K & 31)) return 0;
+    if (p.N % 384) w384 = false;
+    if (p.N % 512) w512 = false;
     if ((p.lda & 7) || (p.ldb & 7) || (p.ldcf & 3) || !p.Cf || p.cf_accumulate || p.act != VG_ACT_NONE) return 0;
     if (p.C || p.C2 || p.bias || p.res || p.resf || p.Z || p.Zf || p.row_in_per > 0 || p.drop_thresh) return 0;
     if ((long long)(p.M + 128) * p.ldcf >= (1LL << 31)) return 0;
     if ((long long)64 * (p.lda > p.ldb ? p.lda : p.ldb) * 2 >= (1LL << 31)) return 0;
   }
+  if (!w384 && !w512) return 0;
+  const int bn = w384 ? 384 : 512;  // one tile width per launch (a group is one kernel)
   VgGemmGroup grp;
   grp.n = n; grp.tpw = 1; grp.zeros = nullptr;
 #ifdef VG_TN_STAMPS
@@ -256,7 +267,7 @@ int vg_gemm_tn384_try(VgGemmProb* probs, int n, hipStream_t stream) {
   for (int i = 0; i < n; ++i) {
     VgGemmProb& p = probs[i];
     p.tiles_m = p.M / 128;
-    p.tiles_n = p.N / 384;
+    p.tiles_n = p.N / bn;
     int splits = p.splits > 0 ? p.splits : 1;
     const int ksteps = p.K / 32;
     const int per = (ksteps + splits - 1) / splits;
@@ -268,7 +279,8 @@ int vg_gemm_tn384_try(VgGemmProb* probs, int n, hipStream_t stream) {
     grp.p[i] = p;
   }
   grp.total = total;
-  hipLaunchKernelGGL(vg_gemm_tn384_kernel, dim3(total), dim3(512), 0, stream, grp);
+  if (w384) hipLaunchKernelGGL(vg_gemm_tn384_kernel<6>, dim3(total), dim3(512), 0, stream, grp);
+  else hipLaunchKernelGGL(vg_gemm_tn384_kernel<8>, dim3(total), dim3(512), 0, stream, grp);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }
