@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 4
+#define VG_ABI_VERSION 5
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -77,6 +77,28 @@ int vg_sln_bwd(const void* dy, const void* h, int h_bcast_rows, const void* w, c
                const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                const void* gres, void* dh, float* dw_acc, int dw_accumulate, float* part, int R,
                int E, void* stream);
+/* Linear + LayerNorm in ONE kernel, for the Linears whose output is the embedding width 384 (rows owned whole by a
+ * workgroup, statistics in the epilogue; csrc/gemm_row.hip).  M % 16 == 0, K % 64 == 0, K >= 128; other shapes return -3
+ * (vg_row_parts(M) == 0 says so beforehand) and the caller uses vg_linear_* + vg_layernorm_*.
+ * The weight operand is PACKED first: Wp = vg_row_pack_weight(W): [K/32][384][32] stage images, vg_row_pack_elems(K) bf16;
+ *   transposed = 0: W is [384, K] row-major with leading dimension ld (nn.Linear weight whose out_features is 384: forward);
+ *   transposed = 1: W is [K, 384] (nn.Linear weight whose in_features is 384: its input gradient dX = dY W).
+ * vg_linear_ln_fwd:  Y = res + drop(A Wp^T + bias);  Yn = LayerNorm(Y) * gamma + beta, mean / rstd of Y   (Yn NULL: Y only)
+ *   replaces out_projection / fc2 + dropout + residual add + the LayerNorm that reads the sum (src/v2/modules.py:168,172,179-183).
+ *   drop(.) is dropout site `site` of (drop_p, seed) as in vg_dropout_apply (drop_p = 0: none).
+ * vg_linear_dgrad_ln_bwd:  dx = gres + LayerNorm'(dY Wp);  dxm = dx * mask(site) (NULL: none);
+ *   part: fp32 [vg_row_parts(M)][3*384] per-workgroup column sums d gamma | d beta | colsum(dxm ? dxm : dx), fold with vg_colsum_f32
+ *   replaces autograd of queries|keys|values / fc1 and of the LayerNorm in front of them (modules.py:178-181). */
+long long vg_row_pack_elems(int K); /* host only */
+int vg_row_pack_weight(const void* W, int ld, int K, int transposed, void* Wp, void* stream);
+int vg_row_parts(int M);            /* host only */
+int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
+                     float* rstd, const float* gamma, const float* beta, int M, int K, float eps, float drop_p,
+                     unsigned long long seed, int site, const unsigned* step_dev, void* stream);
+int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
+                           const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
+                           float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
+
 /* dst_k[c] (+)= sum_r part[r][off_k + c] for up to 4 consecutive column segments (NULL = skip). */
 int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1,
                   float* d2, int n2, float* d3, int n3, int accumulate, void* stream);

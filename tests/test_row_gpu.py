@@ -1,0 +1,181 @@
+"""Parity of the full-row Linear + LayerNorm kernels (csrc/gemm_row.hip, through the C ABI) against fp32 PyTorch.
+
+vg_linear_ln_fwd replaces out_projection / fc2 + dropout + residual + the LayerNorm that reads the sum
+(src/v2/modules.py:168,172,179-183); vg_linear_dgrad_ln_bwd replaces autograd of queries|keys|values / fc1 and of the
+LayerNorm in front of them (modules.py:178-181).  Inputs are rounded to bf16 first; the kernels round the GEMM result to
+bf16 once (as the unfused kernels did at their HBM round trip), so the references do the same: tolerance 2^-7 of max|ref|
+for bf16 outputs (plus one ulp of the intermediate), 3e-5 for fp32 statistics, 1e-4 for the column sums.
+
+Row counts: M = 16 * units over min(256, ceil(units / 4)) workgroups - the sizes below give tiles of 1..9 m-tiles, several
+tiles per workgroup (M = 66 560: 16-17 units each) and the full C2 launches (M = 16 640 / 33 280: 4-5 and 8-9 units)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF_TOL = 2.0 ** -7
+E = 384
+
+
+def _u():
+    import gpu_util
+    return gpu_util
+
+
+def _pack(u, W, K, transposed):
+    L = u._lib.lib()
+    n = L.vg_row_pack_elems(K)
+    assert n == E * K
+    Wp = torch.empty(n, dtype=u.BF, device="cuda")
+    dW = u.dev(W, u.BF)
+    u.call("vg_row_pack_weight", u.ptr(dW), W.shape[1], K, 1 if transposed else 0, u.ptr(Wp), u.stream())
+    return Wp
+
+
+def _mask(u, M, p, seed, site):
+    ones = torch.ones(M, E, dtype=u.BF, device="cuda")
+    m = torch.empty_like(ones)
+    u.call("vg_dropout_apply", u.ptr(ones), u.ptr(m), M * E, p, seed, site, None, u.stream())
+    u.sync()
+    return m.float().cpu()
+
+
+SHAPES = [(16, 384), (48, 768), (1040, 384), (2080, 1152), (2096, 768), (4160, 768), (16640, 384), (16640, 1152),
+          (33280, 768), (33280, 1152), (66560, 384)]
+
+
+@pytest.mark.parametrize("M,K", SHAPES)
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_linear_ln_fwd(M, K, drop):
+    u = _u()
+    g = torch.Generator().manual_seed(M + K)
+    A = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(E, K, generator=g) / math.sqrt(K))
+    b = torch.randn(E, generator=g) * 0.1
+    R = u.rbf(torch.randn(M, E, generator=g))
+    gam = 1.0 + 0.2 * torch.randn(E, generator=g)
+    bet = 0.1 * torch.randn(E, generator=g)
+    seed, site = 77, 5
+    y = A @ W.t() + b
+    if drop:
+        y = y * _mask(u, M, drop, seed, site)
+    y = u.rbf(y + R)  # the stored sum is bf16, and the statistics are those of the stored values
+    yn = F.layer_norm(y, (E,), gam, bet, 1e-5)
+    mu = y.mean(1)
+    rs = 1.0 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+
+    Wp = _pack(u, W, K, False)
+    dA, db, dR, dg, dbt = u.dev(A, u.BF), u.dev(b), u.dev(R, u.BF), u.dev(gam), u.dev(bet)
+    Y = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    Yn = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    u.call("vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(dg), u.ptr(dbt),
+           M, K, 1e-5, drop, seed, site, None, u.stream())
+    u.sync()
+    u.assert_close(Y[:M], y, BF_TOL, "Y")
+    # LayerNorm of a sum that may differ by one bf16 ulp from the reference's: compare against the LayerNorm of the kernel's own Y too
+    yk = Y[:M].float().cpu()
+    u.assert_close(Yn[:M], F.layer_norm(yk, (E,), gam, bet, 1e-5), BF_TOL, "Yn vs LN(own Y)")
+    u.assert_close(mean, yk.mean(1), 3e-5, "mean", floor=1e-6)
+    u.assert_close(rstd, 1.0 / torch.sqrt(yk.var(1, unbiased=False) + 1e-5), 3e-5, "rstd")
+    u.assert_close(Yn[:M], yn, 2.0 ** -5, "Yn vs reference")
+    u.assert_close(mean, mu, 2.0 ** -6, "mean vs reference", floor=1e-3)
+    u.assert_close(rstd, rs, 2.0 ** -7, "rstd vs reference")
+    assert bool((Y[M:] == 7.0).all()) and bool((Yn[M:] == 7.0).all()), "rows beyond M were written"
+    # without a LayerNorm behind it (the last block's fc2)
+    Y2 = torch.empty(M, E, dtype=u.BF, device="cuda")
+    u.call("vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y2), None, None, None, None, None,
+           M, K, 1e-5, drop, seed, site, None, u.stream())
+    u.sync()
+    assert torch.equal(Y2, Y[:M])
+
+
+@pytest.mark.parametrize("M,K", SHAPES)
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_linear_dgrad_ln_bwd(M, K, drop):
+    u = _u()
+    g = torch.Generator().manual_seed(M * 3 + K)
+    dY = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(K, E, generator=g) / math.sqrt(K))  # nn.Linear(E, K).weight: the Linear the LayerNorm feeds
+    x = u.rbf(torch.randn(M, E, generator=g) * 1.5 + 0.3)
+    gres = u.rbf(torch.randn(M, E, generator=g))
+    gam = 1.0 + 0.2 * torch.randn(E, generator=g)
+    seed, site = 31, 2
+    mu = x.mean(1, keepdim=True)
+    rs = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xh = (x - mu) * rs
+    dxn = u.rbf(dY @ W)  # the input gradient of the Linear is rounded to bf16 once (the unfused pair stored it)
+    gg = dxn * gam
+    dx = u.rbf(gres + rs * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)))
+    dxm = u.rbf(dx * _mask(u, M, drop, seed, site)) if drop else None
+    terms = [dxn * xh, dxn, dxm if drop else dx]
+    parts_ref = torch.cat([t.sum(0) for t in terms])
+
+    WpT = _pack(u, W, K, True)
+    L = u._lib.lib()
+    nparts = L.vg_row_parts(M)
+    assert nparts >= 1
+    d_dY, d_x, d_gres, d_gam = u.dev(dY, u.BF), u.dev(x, u.BF), u.dev(gres, u.BF), u.dev(gam)
+    d_mu, d_rs = u.dev(mu.flatten()), u.dev(rs.flatten())
+    out = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    outm = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    part = torch.full((nparts + 1, 3 * E), 7.0, device="cuda")
+    u.call("vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out),
+           u.ptr(outm) if drop else None, u.ptr(part), M, K, drop, seed, site, None, u.stream())
+    u.sync()
+    u.assert_close(out[:M], dx, BF_TOL * 1.5, "dx")  # one ulp of the bf16 d x_hat on top of the output rounding
+    if drop:
+        u.assert_close(outm[:M], dxm, BF_TOL * 1.5, "dxm")
+    assert bool((out[M:] == 7.0).all()) and bool((part[nparts:] == 7.0).all()), "written past the end"
+    got = part[:nparts].sum(0).cpu()
+    for i, name in enumerate(("d gamma", "d beta", "colsum")):
+        ref = parts_ref[i * E:(i + 1) * E]
+        scale = float(ref.abs().max())
+        # sums of M terms that each may differ by one bf16 ulp (2^-8 of the term): random-walk growth, 1.5 sigma-ish headroom
+        tol = 2.0 ** -8 * math.sqrt(M) * 1.5 * float(terms[i].abs().max()) + 1e-4 * scale
+        assert float((got[i * E:(i + 1) * E] - ref).abs().max()) <= tol, name
+    # bitwise repeatable (no atomics, fixed fold order)
+    out2 = torch.empty_like(out)
+    part2 = torch.empty_like(part)
+    u.call("vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out2),
+           None, u.ptr(part2), M, K, 0.0, seed, site, None, u.stream())
+    u.sync()
+    assert torch.equal(out2[:M], out[:M]) and torch.equal(part2[:nparts, :2 * E], part[:nparts, :2 * E])
+
+
+def test_row_kernel_rejects_unsupported_shapes():
+    u = _u()
+    L = u._lib.lib()
+    assert L.vg_row_parts(130) == 0 and L.vg_row_parts(8) == 0 and L.vg_row_parts(16) == 1 and L.vg_row_parts(33280) == 256
+    assert L.vg_row_pack_elems(48) == -2
+    a = torch.zeros(130, 384, dtype=u.BF, device="cuda")
+    wp = torch.zeros(384 * 384, dtype=u.BF, device="cuda")
+    y = torch.zeros(130, 384, dtype=u.BF, device="cuda")
+    rc = L.vg_linear_ln_fwd(a.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), None, None, None, None, None, 130, 384, 1e-5, 0.0, 0, 0, None,
+                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -3
+
+
+@pytest.mark.parametrize("M,K", [(33280, 1152), (16640, 768)])
+def test_row_kernel_race_screen(M, K):
+    """The ring protocol (counted vmcnt per wave, one barrier per stage, fragments a stage ahead) under repetition: 40 launches of
+    the same problem must be bit-identical (an early fragment read or a late DMA shows as a rare differing tile)."""
+    u = _u()
+    g = torch.Generator().manual_seed(5)
+    A = u.dev(torch.randn(M, K, generator=g), u.BF)
+    W = torch.randn(E, K, generator=g) / math.sqrt(K)
+    Wp = _pack(u, u.rbf(W), K, False)
+    R = u.dev(torch.randn(M, E, generator=g), u.BF)
+    outs = []
+    for i in range(40):
+        Y = torch.empty(M, E, dtype=u.BF, device="cuda")
+        u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), None, u.ptr(R), u.ptr(Y), None, None, None, None, None, M, K, 1e-5, 0.0, 0, 0, None, u.stream())
+        outs.append(Y)
+    u.sync()
+    for i in range(1, 40):
+        assert torch.equal(outs[0], outs[i]), f"launch {i} differs"

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VITGAN_HIP_LIB", os.path.join(_HERE, "libvitgan_hip.s
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
-ABI_VERSION = 4  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
+ABI_VERSION = 5  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
 
 
 class VgVitDims(C.Structure):
@@ -73,6 +73,11 @@ _SIGNATURES = {
     "vg_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "vg_sln_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_float, P]),
     "vg_sln_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, P]),
+    "vg_row_pack_elems": (c_ll, [c_int]),
+    "vg_row_pack_weight": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "vg_row_parts": (c_int, [c_int]),
+    "vg_linear_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_dgrad_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
     "vg_colsum_bf16_parts": (c_int, [c_int]),
     "vg_colsum_bf16": (c_int, [P, c_ll, c_int, c_int, P, P, c_int, P]),

@@ -1,6 +1,7 @@
 // extern "C" single-operator entry points of include/vitgan_hip.h (thin argument adapters).
 #include "../../include/vitgan_hip.h"
 #include "vg_kernels.h"
+#include "vg_row.h"
 
 extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
 
@@ -80,10 +81,46 @@ extern "C" int vg_dropout_apply(const void* x, void* y, long long n, float p, un
                                 const unsigned* step_dev, void* stream) {
   if (!x || !y || n < 1 || p < 0.f || p >= 1.f) return -1;
   int t = (int)lrintf(p * 256.f); if (t > 255) t = 255;
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-  return vg_dropout_apply_launch((const bf16*)x, (bf16*)y, n, (unsigned)t, (unsigned)(z ^ (z >> 32)), t ? 256.f / (256.f - t) : 1.f,
+  return vg_dropout_apply_launch((const bf16*)x, (bf16*)y, n, (unsigned)t, vg_site_key(seed, site), t ? 256.f / (256.f - t) : 1.f,
                                  step_dev, (hipStream_t)stream);
+}
+// ---- full-row Linear + LayerNorm (gemm_row.hip) ----
+extern "C" long long vg_row_pack_elems(int K) { return (K < 32 || (K & 31)) ? -2 : (long long)VG_ROW_N * K; }
+extern "C" int vg_row_pack_weight(const void* W, int ld, int K, int transposed, void* Wp, void* stream) {
+  if (!W || !Wp) return -1;
+  VgPackJobs pj;
+  pj.src = (const bf16*)W; pj.dst = (bf16*)Wp; pj.src_stride = 0; pj.dst_stride = 0; pj.nblocks = 1; pj.n = 1;
+  pj.d[0] = {0, 0, K, ld, transposed ? 1 : 0};
+  return vg_pack_rows_launch(pj, (hipStream_t)stream);
+}
+extern "C" int vg_row_parts(int M) { return vg_row_nwg(M); }
+static void row_drop(VgRowArgs& ra, float p, unsigned long long seed, int site, const unsigned* step_dev) {
+  int t = (int)lrintf(p * 256.f); if (t < 0) t = 0; if (t > 255) t = 255;
+  if (!t) return;
+  ra.drop_thresh = (unsigned)t; ra.drop_key = vg_site_key(seed, site); ra.drop_scale = 256.f / (256.f - t); ra.drop_step = step_dev;
+}
+extern "C" int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
+                                float* rstd, const float* gamma, const float* beta, int M, int K, float eps, float drop_p,
+                                unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  if (!A || !Wp || !Y || (Yn && (!mean || !rstd || !gamma || !beta)) || drop_p < 0.f || drop_p >= 1.f) return -1;
+  VgRowArgs ra = {};
+  ra.A = (const bf16*)A; ra.lda = K; ra.Wp = (const bf16*)Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = (const bf16*)res;
+  ra.Y = (bf16*)Y; ra.Yn = (bf16*)Yn; ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = eps;
+  row_drop(ra, drop_p, seed, site, step_dev);
+  const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
+extern "C" int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
+                                      const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
+                                      float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  if (!dY || !WpT || !x || !mean || !rstd || !gamma || !dx || !part || drop_p < 0.f || drop_p >= 1.f) return -1;
+  VgRowArgs ra = {};
+  ra.A = (const bf16*)dY; ra.lda = K; ra.Wp = (const bf16*)WpT; ra.M = M; ra.K = K; ra.x = (const bf16*)x; ra.mean = mean; ra.rstd = rstd;
+  ra.gamma = gamma; ra.gres = (const bf16*)gres; ra.dx = (bf16*)dx; ra.dxm = (bf16*)dxm; ra.part = part;
+  if (dxm) row_drop(ra, drop_p, seed, site, step_dev);
+  if (dxm && !ra.drop_thresh) { ra.drop_thresh = 0; ra.drop_scale = 1.f; }
+  const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
 extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;

@@ -10,6 +10,7 @@
 //                      their split-K wgrad slabs fold into G with a single streaming kernel.
 #include "../../include/vitgan_hip.h"
 #include "vg_kernels.h"
+#include "vg_row.h"
 
 static inline long long al64(long long x) { return (x + 63) & ~63LL; }
 
@@ -151,11 +152,7 @@ static Drop mk_drop(float p, unsigned long long seed, const unsigned* step) {
   Drop d; int t = (int)lrintf(p * 256.f); if (t < 0) t = 0; if (t > 255) t = 255;
   d.thr = (unsigned)t; d.scale = t ? 256.f / (256.f - (float)t) : 1.f; d.seed = seed; d.step = step; return d;
 }
-static unsigned site_key(const Drop& d, int site) {  // splitmix64 of (seed, site) folded to 32 bits
-  unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-  return (unsigned)(z ^ (z >> 32));
-}
+static unsigned site_key(const Drop& d, int site) { return vg_site_key(d.seed, site); }
 static void set_drop(VgGemmProb& p, const Drop& d, int site, int post) {
   if (!d.thr) return;
   p.drop_thresh = d.thr; p.drop_key = site_key(d, site); p.drop_scale = d.scale; p.drop_post = post; p.drop_step = d.step;
@@ -226,7 +223,11 @@ struct VitWs {
   float* bslab;   // [L][VIT_SPLIT_CAP][3E + rE + E] bias-gradient rows written by the weight-gradient GEMM, one per K slice
   bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *tok_sum, *slab;
+  bf16* wpack;  // E = 384: stage images of Wo | W2 | Wqkv^T | W1^T per block for the full-row GEMMs (gemm_row.hip)
 };
+// The full-row GEMMs (LayerNorm in the epilogue) take the block Linears whose output is the embedding when E = 384 and the
+// rows come in whole units of 16; their workgroup count is also the number of LayerNorm-backward partial rows.
+static inline int vit_row_nwg(const VgVitDims& d, int M) { return d.E == VG_ROW_N ? vg_row_nwg(M) : 0; }
 static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   const long long E = d.E, NP = (long long)(d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = (long long)B * S;
   const long long Kp = (long long)d.C * d.P * d.P, L = d.L, rE = (long long)d.R * E;
@@ -266,6 +267,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   long long slab = VIT_SPLIT_CAP * lay.layer_weights;
   if (EMB_SPLIT_CAP * E * Kp > slab) slab = EMB_SPLIT_CAP * E * Kp;
   w.slab = c.take<float>(slab);
+  w.wpack = c.take<bf16>(vit_row_nwg(d, (int)M) ? L * lay.layer_weights : 0);
   return c.off;
 }
 extern "C" long long vg_vit_ws_bytes(const VgVitDims* d, int B) {
@@ -316,6 +318,28 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   }
   VG_TRY(vg_fill_cls_launch(w.X, P + lay.cls, B, S, E, dr.thr, site_key(dr, 0), dr.scale, dr.step, st));
 
+  // full-row path: pack this call's weights (the backward of this workspace reads the transposed images)
+  const int rown = vit_row_nwg(d, M);
+  const long long po_wo = 0, po_w2 = po_wo + (long long)E * E, po_wqkvT = po_w2 + (long long)E * rE, po_w1T = po_wqkvT + 3LL * E * E;
+  if (rown) {
+    VgPackJobs pj;
+    pj.src = Pb + lay.layer0; pj.dst = w.wpack; pj.src_stride = lay.layer_stride; pj.dst_stride = lay.layer_weights; pj.nblocks = d.L; pj.n = 4;
+    pj.d[0] = {lay.wo, po_wo, E, E, 0};          // out-projection forward: W [E, E], contraction E
+    pj.d[1] = {lay.w2, po_w2, rE, rE, 0};        // fc2 forward: W [E, rE], contraction rE
+    pj.d[2] = {lay.wqkv, po_wqkvT, 3 * E, E, 1}; // QKV input gradient: W [3E, E] read transposed, contraction 3E
+    pj.d[3] = {lay.w1, po_w1T, rE, E, 1};        // fc1 input gradient: W [rE, E] read transposed, contraction rE
+    VG_TRY(vg_pack_rows_launch(pj, st));
+  }
+  auto row_fwd = [&](const bf16* A, int K, const bf16* Wp, const float* bias, const bf16* res, bf16* Y, bf16* Yn, float* mean,
+                     float* rstd, const float* gamma, const float* beta, int site) -> int {
+    VgRowArgs ra = {};
+    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = res; ra.Y = Y; ra.Yn = Yn;
+    ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = 1e-5f;
+    if (dr.thr) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
+    const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, st);
+    return r > 0 ? 0 : (r < 0 ? -r : -3);
+  };
+
   for (int l = 0; l < d.L; ++l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* x = w.X + (size_t)l * ME;
@@ -326,17 +350,33 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     bf16* xn2 = w.xn2 + (size_t)l * ME;
     bf16* z1 = w.z1 + (size_t)l * M * rE;
     bf16* a1 = w.a1 + (size_t)l * M * rE;
-    VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
-                            w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
+    const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
+    // norm1: standalone for block 0 (and on the tiled path); on the full-row path the fc2 epilogue of block l-1 wrote it
+    if (!rown || l == 0)
+      VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
+                              w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
     VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
-    VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
-    VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
-                            w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
+    if (rown) {  // x_mid = x + drop(out_projection(ao)) and norm2(x_mid) in one kernel
+      VG_TRY(row_fwd(ao, E, wp + po_wo, P + lo + lay.bo, x, xmid, xn2, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M,
+                     P + lo + lay.ln2_w, P + lo + lay.ln2_b, 1 + 2 * l));
+    } else {
+      VG_TRY(lin_fwd(ao, E, Pb + lo + lay.wo, P + lo + lay.bo, xmid, M, E, VG_ACT_NONE, 0.f, x, nullptr, nullptr, st, &dr, 1 + 2 * l));
+      VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
+                              w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
+    }
     // z1 keeps gelu'(pre-activation), the only thing the backward needs of it
     VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st, nullptr, 0, 1));
-    VG_TRY(lin_fwd(a1, rE, Pb + lo + lay.w2, P + lo + lay.b2, w.X + (size_t)(l + 1) * ME, M, E, VG_ACT_NONE, 0.f, xmid,
-                   nullptr, nullptr, st, &dr, 2 + 2 * l));
+    if (rown) {  // X[l+1] = x_mid + drop(fc2(a1)) and the NEXT block's norm1 of it (the last block's output only feeds the CLS rows)
+      const bool nx = l + 1 < d.L;
+      const long long ln = lo + lay.layer_stride;
+      VG_TRY(row_fwd(a1, rE, wp + po_w2, P + lo + lay.b2, xmid, w.X + (size_t)(l + 1) * ME, nx ? w.xn1 + (size_t)(l + 1) * ME : nullptr,
+                     nx ? w.mean1 + (size_t)(l + 1) * M : nullptr, nx ? w.rstd1 + (size_t)(l + 1) * M : nullptr,
+                     nx ? P + ln + lay.ln1_w : nullptr, nx ? P + ln + lay.ln1_b : nullptr, 2 + 2 * l));
+    } else {
+      VG_TRY(lin_fwd(a1, rE, Pb + lo + lay.w2, P + lo + lay.b2, w.X + (size_t)(l + 1) * ME, M, E, VG_ACT_NONE, 0.f, xmid,
+                     nullptr, nullptr, st, &dr, 2 + 2 * l));
+    }
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
@@ -364,9 +404,21 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   VitWs w; carve_vit(d, B, ws, w);
   const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
   const size_t ME = (size_t)M * E;
-  const int lnparts = vg_ln_bwd_nparts(M);
+  const int rown = vit_row_nwg(d, M);  // full-row path: the forward packed the weights into this workspace
+  const int lnparts = rown ? rown : vg_ln_bwd_nparts(M);
+  const long long po_wqkvT = (long long)E * E + (long long)E * rE, po_w1T = po_wqkvT + 3LL * E * E;
   const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
   const bool drop = dr.thr != 0;
+  // dx = gres + LayerNorm'(A W) in one kernel (gemm_row.hip)
+  auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma,
+                     const bf16* gres, bf16* dx, bf16* dxm, float* part, int site) -> int {
+    VgRowArgs ra = {};
+    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
+    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = part;
+    if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
+    const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, st);
+    return r > 0 ? 0 : (r < 0 ? -r : -3);
+  };
   VgCtx* ctx = (VgCtx*)net->ctx;
   hipStream_t sd = ctx ? ctx->side : st;  // stream of the weight-gradient side work
   const int top = d.L - 1;
@@ -382,7 +434,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   }
   VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
   VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st));
-  if (want_wgrad)
+  if (want_wgrad)  // (the final LayerNorm's own partial count: B rows, standalone kernel)
     VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
   VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st));
   if (drop) VG_TRY(vg_dropout_apply_launch(w.set[top & 1].gin, w.set[top & 1].gm2, (long long)M * E, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step, st));
@@ -413,19 +465,30 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     // ---------------- input-gradient chain (main stream) ----------------
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z, z1, nullptr, 0.f, st));
-    VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, part2, M, E,
-                            drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
+    if (rown) {  // fc1 input gradient + norm2 backward + the residual-stream gradient
+      VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid,
+                     drop ? cur.gm1 : nullptr, part2, 1 + 2 * l));
+    } else {
+      VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, part2, M, E,
+                              drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    }
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
-    VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    if (!rown) VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     // LN1 backward writes dL/dX[l] (and its masked copy for the dropout it meets next) into the OTHER set, which the
     // weight-gradient side of block l+1 may still be reading: wait for it first
     if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
       VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[l + 1], 0));
-    VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, part1, M, E,
-                            drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+    if (rown) {  // QKV input gradient + norm1 backward + the residual-stream gradient
+      VG_TRY(row_bwd(cur.dqkv, 3 * E, wp + po_wqkvT, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin,
+                     drop ? nxt.gm2 : nullptr, part1, l > 0 ? 2 + 2 * (l - 1) : 0));
+    } else {
+      VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, part1, M, E,
+                              drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+    }
     if (!want_wgrad) continue;
     // ---------------- weight-gradient side (second stream when a context is given) ----------------
     if (ctx) {

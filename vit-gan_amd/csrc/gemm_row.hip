@@ -1,0 +1,456 @@
+// Full-row GEMM for the Linears whose OUTPUT is the embedding width (N = 384), with the LayerNorm next to them in the
+// epilogue.  gfx950 only.
+//
+//   VG_ROW_LNFWD   y = res + drop(A W^T + b);  yn = LayerNorm(y)          out-projection (K = 384) and fc2 (K = 768) of a block
+//                  (src/v2/modules.py:179-183: the residual adds, and norm2 / the next block's norm1 at :168,172)
+//   VG_ROW_LNBWD   dx = gres + LayerNorm'(A W);  dxm = dx * mask           fc1 (K = 768) and QKV (K = 1152) input gradients +
+//                  the backward of the LayerNorm that fed them (autograd of :178-181)
+//
+// Why: the standalone LayerNorm kernels were 70 launches and 15 % of the step, and each moved a [M, 384] tensor through HBM
+// only to re-read it in the next launch.  A LayerNorm needs whole rows, so a workgroup here owns whole rows: 8 waves side by
+// side along n (48 columns = 3 MFMA tiles each) over MT <= 9 m-tiles (16 MT rows), one workgroup per CU.  Rows are dealt in
+// units of 16: M = 65 * 2^k never divides into 128-row tiles over 256 CUs (260 tiles = two rounds, the second one empty), 2080
+// units over 256 workgroups are 8 or 9 each - one tile per workgroup at 89 % balance.
+//
+// Operands: the weight comes PACKED (vg_pack_rows_kernel): one 24-KiB image per 32-deep k-stage, [384 n][32 k] with the
+// row-form XOR swizzle already applied, transposed on the way for the input gradients - so a W stage is 24 fully contiguous
+// 1-KiB LDS-DMA pieces (full 128-byte lines: half-line pieces cost a whole request each) and both passes are the
+// NT form with ds_read_b128 fragments (10-12 reads per 24-27 MFMAs; the transposing reads of the NN form were what limited
+// gemm_tn.hip).  A is staged per stage as [16 MT rows][32 k].  4-slot ring, two stages in flight, fragments of stage s+1
+// requested before the MFMAs of stage s, the two waves of a SIMD in opposite order - the protocol of gemm_tn.hip.
+//
+// Epilogue: the accumulators go to LDS once as a bf16 tile [16 MT][384] (the ring is free by then) - exactly the rounding
+// the unfused pair had at its HBM round trip - and are re-read row-wise, 16 lanes per row, by the LayerNorm code of norm.hip:
+// every global access of the epilogue is then a whole 768-byte row in 16-byte pieces.
+#include "vg_row.h"
+#include <type_traits>
+
+namespace {
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int RW_E = VG_ROW_N;
+constexpr int RW_WIMG = RW_E * 64;                     // one W stage image: 384 rows x 64 B
+constexpr int RW_MAXMT = 9;
+constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
+constexpr int RW_NSLOT = 4;
+constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
+constexpr int RW_TS = 784;                             // row stride of the epilogue tile: 768 + 16 (ds_write_b64 2-way at worst)
+static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
+static_assert(3 * 8 * RW_E * 4 <= RW_RING, "column-sum fold must fit the ring");
+
+// row-form chunk swizzle of gemm.hip: 16-B chunk c of row r lives at position c ^ {0,2,3,1}[(r>>2)&3]
+__device__ __host__ __forceinline__ int rw_row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
+
+__device__ __forceinline__ void rw_wait_vm(int n) {  // n is wave-uniform (scalar branch)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+__device__ __forceinline__ float rw_row16_sum(float v) {  // sum over the 16 lanes of a row group
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+  return v;
+}
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wid >> 2;  // the two waves of a SIMD are w and w + 4
+  const int u0 = (int)((long long)blockIdx.x * a.units / a.nwg), u1 = (int)((long long)(blockIdx.x + 1) * a.units / a.nwg);
+  if (u0 >= u1) return;  // never: the launcher keeps nwg <= units
+  const int nsteps = a.K >> 5;
+  const int g = lane >> 4, li = lane & 15;
+  const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
+  // fragment addresses inside a stage: W rows 48 wid + 16 nt + li, A rows 16 mt + li; the swizzle only sees li
+  const unsigned fsw = (unsigned)((g ^ rw_row_f(li)) << 4);
+  const unsigned fw = sbase + (unsigned)((48 * wid + li) * 64) + fsw;     // n-tile nt at + 1024 nt
+  const unsigned fa = sbase + (unsigned)(RW_WIMG + li * 64) + fsw;        // m-tile mt at + 1024 mt
+  // LDS-DMA lane offsets: W pieces are contiguous; an A piece is 16 rows x 64 B, position lane&3 of row lane>>2 holds
+  // chunk (lane&3) ^ f(row)
+  const unsigned offW = (unsigned)lane * 16u;
+  const unsigned offA = ((unsigned)(lane >> 2) * (unsigned)a.lda + (unsigned)(((lane & 3) ^ rw_row_f(lane >> 2)) << 3)) * 2u;
+  const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
+
+  float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
+
+  auto tile = [&](auto mt_c, const int m0) {
+    constexpr int MT = decltype(mt_c)::value;
+    const int pps = 3 + (wid < MT ? 1 : 0) + ((MT == 9 && wid == 0) ? 1 : 0);  // LDS-DMA pieces of this wave per stage
+    const char* wptr = (const char*)a.Wp + 1024 * wid;
+    const char* aptr = (const char*)a.A + ((long long)(m0 + 16 * wid) * a.lda) * 2;
+    auto issue = [&](int slot) {
+      asm volatile("" : "+s"(wptr), "+s"(aptr));
+      unsigned char* d = smem + slot * RW_STAGE + 1024 * wid;
+      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + offW), (lptr_t)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + 8192 + offW), (lptr_t)(d + 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + 16384 + offW), (lptr_t)(d + 16384), 16, 0, 0);
+      if (wid < MT) __builtin_amdgcn_global_load_lds((gptr_t)(aptr + offA), (lptr_t)(d + RW_WIMG), 16, 0, 0);
+      if (MT == 9 && wid == 0) __builtin_amdgcn_global_load_lds((gptr_t)(aptr + a8 + offA), (lptr_t)(d + RW_WIMG + 8192), 16, 0, 0);
+      wptr += RW_WIMG; aptr += 64;
+    };
+    struct Frags { u32x4 w[3]; u32x4 m[MT]; };
+    auto read_frags = [&](Frags& f, int slot) {
+      const unsigned so = (unsigned)(slot * RW_STAGE);
+      const unsigned w0 = fw + so, a0 = fa + so;
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.w[nt]) : "v"(w0), "n"(1024 * nt) : "memory");
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.m[mt]) : "v"(a0), "n"(1024 * mt) : "memory");
+    };
+    auto wait_frags = [&](Frags& f) {  // the registers are tied behind the wait: no use of them can be scheduled above it
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2])::"memory");
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(f.m[mt])::"memory");
+    };
+
+    f32x4 acc[3][MT];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: three stages in flight, fragments of stage 0 ----
+    issue(0); issue(1); issue(2);
+    rw_wait_vm(2 * pps);
+    asm volatile("s_barrier" ::: "memory");
+    Frags f0, f1;
+    read_frags(f0, 0);
+
+    // One stage (gemm_tn.hip): B(s) = stage s+1 landed and nobody reads stage s-1 any more; DMA of stage s+3 into the slot
+    // stage s-1 left; fragment reads of stage s+1 into the other register set; this stage's MFMAs.
+    auto stage = [&](Frags& cur, Frags& nxt, int s) {
+      if (s + 1 < nsteps) {
+        if (s + 2 < nsteps) rw_wait_vm(pps); else rw_wait_vm(0);
+        asm volatile("s_barrier" ::: "memory");
+      }
+      wait_frags(cur);  // requested a stage ago
+      if (half == 0) {
+        if (s + 3 < nsteps) issue((s + 3) & 3);
+        if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      {
+        bf16x8 fm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fm[mt] = __builtin_bit_cast(bf16x8, cur.m[mt]);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          const bf16x8 fn = __builtin_bit_cast(bf16x8, cur.w[nt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = vg_mfma(fn, fm[mt], acc[nt][mt]);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (half != 0) {
+        if (s + 3 < nsteps) issue((s + 3) & 3);
+        if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
+      }
+    };
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 2) {
+      stage(f0, f1, s);
+      stage(f1, f0, s + 1);
+    }
+    // every wave has its last fragments in registers (lgkmcnt(0) above) and no DMA is in flight: the ring is free
+    asm volatile("s_barrier" ::: "memory");
+
+    // ================================ epilogue, phase 1: accumulators -> bf16 tile in LDS ================================
+    // a lane holds C[m = 16 mt + li][n = 48 wid + 16 nt + 4 g + r], r = 0..3
+    if (EPI == VG_ROW_LNFWD) {
+      const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
+      const float dscale = a.drop_scale;
+      f32x4 b4[3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        b4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b4[nt] = *(const f32x4*)(a.bias + 48 * wid + 16 * nt + 4 * g);
+      }
+      bf16x4 rr[3][MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          rr[nt][mt] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+          if (a.res) rr[nt][mt] = *(const bf16x4*)(a.res + (size_t)(m0 + 16 * mt + li) * RW_E + 48 * wid + 16 * nt + 4 * g);
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          const int n = 48 * wid + 16 * nt + 4 * g;
+          f32x4 v = acc[nt][mt] + b4[nt];
+          if (dthr) {
+            const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * mt + li) * (unsigned)RW_E + (unsigned)n) >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= vg_drop_factor(wd, r, dthr, dscale);
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r] + vg_bf2f(rr[nt][mt][r]));
+          *(bf16x4*)(smem + (16 * mt + li) * RW_TS + n * 2) = o;
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          const f32x4 v = acc[nt][mt];
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r]);
+          *(bf16x4*)(smem + (16 * mt + li) * RW_TS + (48 * wid + 16 * nt + 4 * g) * 2) = o;
+        }
+    }
+    __syncthreads();
+
+    // ================================ phase 2: row-wise, 16 lanes per row (norm.hip's layout) ===========================
+    // lane `sub` of a row owns the 16-byte chunks sub, sub + 16, sub + 32; wave w takes rows 4 (8 i + w) + rg
+    const int sub = lane & 15, rg = lane >> 4;
+    constexpr int ROWS = 16 * MT, PASSES = (ROWS + 31) / 32;
+    if (EPI == VG_ROW_LNFWD) {
+      float gam[3][8], bet[3][8];
+      if (a.Yn) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int c = 8 * (sub + 16 * i);
+          const f32x4 g0 = *(const f32x4*)(a.gamma + c), g1 = *(const f32x4*)(a.gamma + c + 4);
+          const f32x4 b0 = *(const f32x4*)(a.beta + c), b1 = *(const f32x4*)(a.beta + c + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; bet[i][j] = b0[j]; bet[i][j + 4] = b1[j]; }
+        }
+      }
+#pragma unroll 1
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int rl = 4 * (8 * ps + wid) + rg;
+        const bool ok = rl < ROWS;
+        const int rc = ok ? rl : 0;
+        const size_t row = (size_t)(m0 + rc);
+        float v[3][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const bf16x8 t = *(const bf16x8*)(smem + rc * RW_TS + 16 * (sub + 16 * i));
+          if (ok) *(bf16x8*)(a.Y + row * RW_E + 8 * (sub + 16 * i)) = t;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[i][j] = vg_bf2f(t[j]); s += v[i][j]; }
+        }
+        if (!a.Yn) continue;
+        const float mu = rw_row16_sum(s) * (1.0f / RW_E);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mu; q += c * c; }
+        const float rs = rsqrtf(rw_row16_sum(q) * (1.0f / RW_E) + a.eps);
+        if (!ok) continue;
+        if (sub == 0) { a.mean_out[row] = mu; a.rstd_out[row] = rs; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = vg_f2bf((v[i][j] - mu) * rs * gam[i][j] + bet[i][j]);
+          *(bf16x8*)(a.Yn + row * RW_E + 8 * (sub + 16 * i)) = o;
+        }
+      }
+    } else {
+      const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
+      const float dscale = a.drop_scale;
+      float gam[3][8], ag[3][8], ab[3][8], ac[3][8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = 8 * (sub + 16 * i);
+        const f32x4 g0 = *(const f32x4*)(a.gamma + c), g1 = *(const f32x4*)(a.gamma + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
+      }
+#pragma unroll 1
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int rl = 4 * (8 * ps + wid) + rg;
+        const bool ok = rl < ROWS;
+        const int rc = ok ? rl : 0;
+        const size_t row = (size_t)(m0 + rc);
+        const float mu = a.mean[row], rs = a.rstd[row];
+        bf16x8 xr[3], gr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          xr[i] = *(const bf16x8*)(a.x + row * RW_E + 8 * (sub + 16 * i));
+          gr[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+          if (a.gres) gr[i] = *(const bf16x8*)(a.gres + row * RW_E + 8 * (sub + 16 * i));
+        }
+        float xh[3][8], gg[3][8];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const bf16x8 t = *(const bf16x8*)(smem + rc * RW_TS + 16 * (sub + 16 * i));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float h = ok ? (vg_bf2f(xr[i][j]) - mu) * rs : 0.f;
+            const float d = ok ? vg_bf2f(t[j]) : 0.f;
+            xh[i][j] = h;
+            ag[i][j] += d * h;
+            ab[i][j] += d;
+            const float gv = d * gam[i][j];
+            gg[i][j] = gv;
+            c1 += gv;
+            c2 += gv * h;
+          }
+        }
+        c1 = rw_row16_sum(c1) * (1.0f / RW_E);
+        c2 = rw_row16_sum(c2) * (1.0f / RW_E);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int c = 8 * (sub + 16 * i);
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(rs * (gg[i][j] - c1 - xh[i][j] * c2) + vg_bf2f(gr[i][j]));
+          if (ok) *(bf16x8*)(a.dx + row * RW_E + c) = o;
+          if (a.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
+            const unsigned i4 = ((unsigned)row * (unsigned)RW_E + (unsigned)c) >> 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const unsigned wd = vg_drop_word(dkey, i4 + q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[4 * q + j] = vg_f2bf(vg_bf2f(o[4 * q + j]) * vg_drop_factor(wd, j, dthr, dscale));
+            }
+            if (ok) *(bf16x8*)(a.dxm + row * RW_E + c) = o;
+          }
+          if (ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ac[i][j] += vg_bf2f(o[j]);
+          }
+        }
+      }
+      // fold the column sums: the 4 row groups of a wave (shuffles), then the 8 waves (LDS, over the tile), fixed order
+      __syncthreads();  // the tile has been read
+      float* red = (float*)smem;  // [3][8][384]
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float sa = ag[i][j], sb = ab[i][j], sc = ac[i][j];
+          sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64); sc += __shfl_xor(sc, 16, 64);
+          sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64); sc += __shfl_xor(sc, 32, 64);
+          if (rg == 0) {
+            const int col = 8 * (sub + 16 * i) + j;
+            red[(0 * 8 + wid) * RW_E + col] = sa; red[(1 * 8 + wid) * RW_E + col] = sb; red[(2 * 8 + wid) * RW_E + col] = sc;
+          }
+        }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = tid + 512 * k;
+        if (c < 3 * RW_E) {
+          const int which = c / RW_E, col = c - which * RW_E;
+          const float* r0 = red + (which * 8) * RW_E + col;
+          cum[k] += ((r0[0] + r0[RW_E]) + (r0[2 * RW_E] + r0[3 * RW_E])) + ((r0[4 * RW_E] + r0[5 * RW_E]) + (r0[6 * RW_E] + r0[7 * RW_E]));
+        }
+      }
+    }
+  };
+
+  int n = u1 - u0, m0 = u0 * 16;
+  bool first = true;
+#pragma unroll 1
+  while (n > 0) {
+    const int mt = n <= RW_MAXMT ? n : 8;
+    if (!first) __syncthreads();  // the previous tile's epilogue has finished with the ring
+    switch (mt) {
+      case 1: tile(std::integral_constant<int, 1>{}, m0); break;
+      case 2: tile(std::integral_constant<int, 2>{}, m0); break;
+      case 3: tile(std::integral_constant<int, 3>{}, m0); break;
+      case 4: tile(std::integral_constant<int, 4>{}, m0); break;
+      case 5: tile(std::integral_constant<int, 5>{}, m0); break;
+      case 6: tile(std::integral_constant<int, 6>{}, m0); break;
+      case 7: tile(std::integral_constant<int, 7>{}, m0); break;
+      case 8: tile(std::integral_constant<int, 8>{}, m0); break;
+      default: tile(std::integral_constant<int, 9>{}, m0); break;
+    }
+    n -= mt; m0 += 16 * mt; first = false;
+  }
+  if (EPI == VG_ROW_LNBWD) {
+    float* out = a.part + (size_t)blockIdx.x * (3 * RW_E);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = tid + 512 * k;
+      if (c < 3 * RW_E) out[c] = cum[k];
+    }
+  }
+}
+
+// ---- weight packing -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vg_pack_rows_kernel(const VgPackJobs J) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk of the block's packed area
+  int q = 0;
+  for (; q < J.n; ++q) {
+    const long long chunks = (long long)RW_E * J.d[q].K / 8;
+    if (t < chunks) break;
+    t -= chunks;
+  }
+  if (q >= J.n) return;
+  const VgPackDesc& D = J.d[q];
+  const int s = (int)(t / (RW_E * 4)), rem = (int)(t - (long long)s * (RW_E * 4));
+  const int n = rem >> 2, pc = rem & 3, c = pc ^ rw_row_f(n), k = 32 * s + 8 * c;
+  const bf16* src = J.src + (long long)blockIdx.y * J.src_stride + D.src_off;
+  bf16* dst = J.dst + (long long)blockIdx.y * J.dst_stride + D.dst_off + t * 8;
+  bf16x8 v;
+  if (!D.transposed) {
+    v = *(const bf16x8*)(src + (size_t)n * D.ld + k);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * D.ld + n];
+  }
+  *(bf16x8*)dst = v;
+}
+
+int vg_pack_rows_launch(const VgPackJobs& jobs, hipStream_t st) {
+  if (jobs.n < 1 || jobs.n > 4 || jobs.nblocks < 1 || !jobs.src || !jobs.dst) return -1;
+  long long chunks = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    const VgPackDesc& d = jobs.d[i];
+    if (d.K < 32 || (d.K & 31) || (d.ld & 7) || (d.src_off & 7) || (d.dst_off & 7)) return -3;
+    chunks += (long long)RW_E * d.K / 8;
+  }
+  if ((jobs.src_stride & 7) || (jobs.dst_stride & 7)) return -3;
+  hipLaunchKernelGGL(vg_pack_rows_kernel, dim3((unsigned)((chunks + 255) / 256), jobs.nblocks), dim3(256), 0, st, jobs);
+  return (int)hipGetLastError();
+}
+
+int vg_row_nwg(int M) {
+  if (M < 16 || (M & 15)) return 0;
+  const int units = M / 16;
+  const int want = (units + 3) / 4;  // at least ~4 units (64 rows) per workgroup while the chip is not full
+  return want < 256 ? want : 256;
+}
+
+int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
+  const int nwg = vg_row_nwg(a.M);
+  if (!nwg || a.K < 128 || (a.K & 63) || (a.lda & 7) || !a.A || !a.Wp) return 0;
+  if ((long long)a.M * RW_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
+  a.units = a.M / 16;
+  a.nwg = nwg;
+  if (epi == VG_ROW_LNFWD) {
+    if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta))) return -1;
+    hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD>), dim3(nwg), dim3(512), 0, st, a);
+  } else if (epi == VG_ROW_LNBWD) {
+    if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || !a.part) return -1;
+    hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD>), dim3(nwg), dim3(512), 0, st, a);
+  } else {
+    return -4;
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 1 : -(int)e;
+}

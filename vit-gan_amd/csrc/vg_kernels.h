@@ -52,6 +52,13 @@ int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_
 int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st);
 int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st);
 
+// dropout key of (seed, site): splitmix64 folded to 32 bits (the engine's site numbering: include/vitgan_hip.h, vg_dropout_apply)
+static inline unsigned vg_site_key(unsigned long long seed, int site) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  return (unsigned)(z ^ (z >> 32));
+}
+
 #define VG_TRY(expr)            \
   do {                          \
     int _rc = (expr);           \

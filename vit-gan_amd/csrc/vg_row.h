@@ -1,0 +1,48 @@
+// Full-row GEMM (gemm_row.hip): C[m, 0:384] = A[m, 0:K] Wp, with the LayerNorm that follows (forward) or precedes
+// (backward) the Linear computed in the epilogue - a workgroup owns whole rows, so the row statistics never leave the CU.
+#pragma once
+#include "vg_common.h"
+
+#define VG_ROW_N 384  // output width of every full-row problem (the embedding width of the C1-C3 configurations)
+
+enum { VG_ROW_LNFWD = 0, VG_ROW_LNBWD = 1 };
+
+struct VgRowArgs {
+  const bf16* A; int lda;  // [M, K] row-major
+  const bf16* Wp;          // packed weights: [K/32][384][32] stage images (vg_pack_rows_launch)
+  int M, K;                // M % 16 == 0, K % 64 == 0
+  int units, nwg;          // 16-row units of A; workgroups (filled by the launcher)
+  // ---- VG_ROW_LNFWD:  y = res + drop(A W^T + bias);  yn = LN(y) * gamma + beta ------------------------------------
+  const float* bias;       // [384] (nullable)
+  const bf16* res;         // [M, 384] (nullable)
+  bf16* Y;                 // [M, 384]
+  bf16* Yn;                // [M, 384] normalised rows; nullptr: no LayerNorm follows (Y only)
+  float* mean_out; float* rstd_out;  // [M] statistics of Y (written when Yn)
+  const float* beta;       // [384]
+  float eps;
+  // ---- VG_ROW_LNBWD:  dx = gres + LN'(A W) ;  dxm = dx * mask -----------------------------------------------------
+  const bf16* x;           // [M, 384] the LayerNorm's input
+  const float* mean; const float* rstd;  // [M]
+  const bf16* gres;        // [M, 384] gradient arriving over the residual connection (nullable)
+  bf16* dx; bf16* dxm;     // [M, 384]; dxm nullable
+  float* part;             // [nwg][3*384]: per workgroup column sums  d gamma | d beta | colsum(dxm ? dxm : dx)
+  // ---- both -------------------------------------------------------------------------------------------------------
+  const float* gamma;      // [384]
+  unsigned drop_thresh, drop_key; float drop_scale; const unsigned* drop_step;  // LNFWD: mask of drop(.); LNBWD: mask of dxm
+};
+
+// number of workgroups (= rows of `part`) a problem of M rows is run with; 0 when the kernel does not take it
+int vg_row_nwg(int M);
+// 1 = enqueued, 0 = not of this kernel's kind, < 0 = -hipError
+int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st);
+
+// Pack up to 4 weight matrices per block, for `nblocks` blocks laid out at a fixed stride, into stage images:
+//   dst[(s * 384 + n) * 32 + ...] <- transposed ? src[(32 s + k) * ld + n] : src[n * ld + 32 s + k]
+struct VgPackDesc { long long src_off, dst_off; int K, ld, transposed; };
+struct VgPackJobs {
+  const bf16* src; bf16* dst;
+  long long src_stride, dst_stride;  // elements between blocks
+  int nblocks, n;
+  VgPackDesc d[4];
+};
+int vg_pack_rows_launch(const VgPackJobs& jobs, hipStream_t st);
