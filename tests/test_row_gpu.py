@@ -179,3 +179,63 @@ def test_row_kernel_race_screen(M, K):
     u.sync()
     for i in range(1, 40):
         assert torch.equal(outs[0], outs[i]), f"launch {i} differs"
+
+
+@pytest.mark.parametrize("K", [384, 1152])
+def test_rows_do_not_depend_on_the_tile_they_land_in(K):
+    """A row's result must be BIT-identical whatever the batch around it: the same 2 080 rows are run as a problem of their own
+    (tiles of 3-4 m-tiles), as the head of 16 640 rows (4-5 m-tiles) and of 33 280 rows (8-9 m-tiles).  The epilogue is
+    instantiated per tile height; this is what catches a multiply-add contracted in one instantiation and not in another."""
+    u = _u()
+    g = torch.Generator().manual_seed(11)
+    Mbig, Ms = 33280, 2080
+    A = u.dev(torch.randn(Mbig, K, generator=g), u.BF)
+    W = u.rbf(torch.randn(E, K, generator=g) / math.sqrt(K))
+    Wp = _pack(u, W, K, False)
+    WpT = _pack(u, u.rbf(torch.randn(K, E, generator=g) / math.sqrt(K)), K, True)
+    R = u.dev(torch.randn(Mbig, E, generator=g), u.BF)
+    X = u.dev(torch.randn(Mbig, E, generator=g) * 1.5 + 0.3, u.BF)
+    gam, bet, b = u.dev(1.0 + 0.2 * torch.randn(E, generator=g)), u.dev(0.1 * torch.randn(E, generator=g)), u.dev(0.1 * torch.randn(E, generator=g))
+    mu = X.float().mean(1).contiguous()
+    rs = (1.0 / torch.sqrt(X.float().var(1, unbiased=False) + 1e-5)).contiguous()
+    L = u._lib.lib()
+    outs = []
+    for M in (Ms, 16640, Mbig):
+        Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
+        mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+        u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
+               M, K, 1e-5, 0.1, 3, 1, None, u.stream())
+        dx = torch.empty(M, E, dtype=u.BF, device="cuda"); dxm = torch.empty_like(dx)
+        part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
+        u.call("vg_linear_dgrad_ln_bwd", u.ptr(A), u.ptr(WpT), u.ptr(X), u.ptr(mu), u.ptr(rs), u.ptr(gam), u.ptr(R), u.ptr(dx), u.ptr(dxm), u.ptr(part),
+               M, K, 0.1, 3, 1, None, u.stream())
+        u.sync()
+        outs.append([t[:Ms].clone() for t in (Y, Yn, mean, rstd, dx, dxm)])
+    for other in outs[1:]:
+        for name, a_, b_ in zip(("Y", "Yn", "mean", "rstd", "dx", "dxm"), outs[0], other):
+            assert torch.equal(a_, b_), name
+
+
+@pytest.mark.parametrize("M,K", [(2080, 384), (16640, 768), (33280, 384)])
+def test_fused_forward_is_bit_identical_to_the_unfused_pair(M, K):
+    """vg_linear_ln_fwd against vg_linear_fwd (+ residual) followed by vg_layernorm_fwd: the sum, the statistics and the
+    normalised rows agree BIT for bit (same k order in the MFMA chains, one rounding of the sum, the statistics written with
+    the arithmetic forms norm.hip compiles to).  This is what lets batches that take the fused path (rows in whole units of 16)
+    and batches that do not (tests/test_fullsize_gpu.py: 8 images) produce identical logits."""
+    u = _u()
+    g = torch.Generator().manual_seed(M + K)
+    A = u.dev(torch.randn(M, K, generator=g), u.BF)
+    W = u.dev(torch.randn(E, K, generator=g) / math.sqrt(K), u.BF)
+    b = u.dev(torch.randn(E, generator=g) * 0.1)
+    R = u.dev(torch.randn(M, E, generator=g), u.BF)
+    gam, bet = u.dev(1 + 0.2 * torch.randn(E, generator=g)), u.dev(0.1 * torch.randn(E, generator=g))
+    Wp = _pack(u, W.float().cpu(), K, False)
+    Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
+    mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+    u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
+           M, K, 1e-5, 0.0, 0, 0, None, u.stream())
+    Y2 = torch.empty_like(Y); Yn2 = torch.empty_like(Y); mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd)
+    u.call("vg_linear_fwd", u.ptr(A), u.ptr(W), u.ptr(b), u.ptr(R), u.ptr(Y2), None, None, M, E, K, 0, 0.0, u.stream())
+    u.call("vg_layernorm_fwd", u.ptr(Y2), E, u.ptr(gam), u.ptr(bet), u.ptr(Yn2), E, u.ptr(mean2), u.ptr(rstd2), M, E, 1e-5, u.stream())
+    u.sync()
+    assert torch.equal(Y, Y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(Yn, Yn2)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of whole-step time between two source TREES on ONE box (a tree = a checkout with its own built library; the ABI
+# version differs between rounds, so the library alone cannot be swapped): bash tools/ab_tree.sh ab_r02 . [bench flags]
+# Alternating runs, three rounds; prints ms_per_step of each run.
+R=${GRAFT_REPO_ROOT:-$PWD}
+A=$R/$1; B=$R/$2; shift 2
+for round in 1 2 3; do
+  for T in $A $B; do
+    ms=$(cd $T && python3 bench.py --no-roofline --no-cpu-baseline --steps 40 --warmup 10 "$@" 2>/dev/null | python3 -c 'import sys,json; print(json.loads(sys.stdin.readlines()[-1])["ms_per_step"])')
+    echo "$(basename $T) $ms"
+  done
+done

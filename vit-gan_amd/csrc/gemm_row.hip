@@ -24,6 +24,13 @@
 // every global access of the epilogue is then a whole 768-byte row in 16-byte pieces.
 #include "vg_row.h"
 #include <type_traits>
+#include <stdlib.h>
+
+// The epilogue arithmetic is instantiated once per tile height (MT = 1..9), and a row lands in tiles of different heights
+// depending on the batch it is part of: with the compiler free to contract a*b+c here and not there, the same row came out
+// one ulp different in a batch of 64 and of 256 (tests/test_fullsize_gpu.py: per-sample bit-independence).  Contraction is
+// therefore OFF in this file and every fused multiply-add is written as fmaf().
+#pragma clang fp contract(off)
 
 namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -31,12 +38,19 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int RW_E = VG_ROW_N;
 constexpr int RW_WIMG = RW_E * 64;                     // one W stage image: 384 rows x 64 B
-constexpr int RW_MAXMT = 9;
+#ifndef RW_MAXMT_
+#define RW_MAXMT_ 9
+#endif
+constexpr int RW_MAXMT = RW_MAXMT_;  // m-tiles per tile (tuning builds: make var DEFS=-DRW_MAXMT_=5)
 constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
 constexpr int RW_NSLOT = 4;
 constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
-constexpr int RW_TS = 784;                             // row stride of the epilogue tile: 768 + 16 (ds_write_b64 2-way at worst)
+constexpr int RW_SINK = 8 * 1024;                      // behind the ring: where the operand-prefetch pieces land (never read)
+constexpr int RW_GAM = RW_E * 4;                       // behind the sink: gamma in fp32 (the LNBWD epilogue has no registers for it)
+constexpr int RW_TS = 784;                             // row stride of the bf16 epilogue tile (LNBWD): 768 + 16 (ds_write_b64 2-way at worst)
+constexpr int RW_TSF = 1552;                           // row stride of the fp32 epilogue tile (LNFWD, 80 rows at a time): 1536 + 16
 static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
+static_assert(80 * RW_TSF <= RW_RING, "fp32 half tile must fit the ring");
 static_assert(3 * 8 * RW_E * 4 <= RW_RING, "column-sum fold must fit the ring");
 
 // row-form chunk swizzle of gemm.hip: 16-B chunk c of row r lives at position c ^ {0,2,3,1}[(r>>2)&3]
@@ -49,54 +63,101 @@ __device__ __forceinline__ void rw_wait_vm(int n) {  // n is wave-uniform (scala
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
-__device__ __forceinline__ float rw_row16_sum(float v) {  // sum over the 16 lanes of a row group
-  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+// Sum over the 16 lanes of a row group, in every lane, by DPP row rotations (8, 4, 2, 1): the association tree - and so the
+// result, bit for bit, in every lane - is that of the xor butterfly of norm.hip, without its four trips through the LDS
+// crossbar (ds_bpermute + lgkmcnt), which nothing hides at two waves per SIMD.
+template <int N>
+__device__ __forceinline__ float rw_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float rw_row16_sum(float v) {
+  v += rw_ror<8>(v); v += rw_ror<4>(v); v += rw_ror<2>(v); v += rw_ror<1>(v);
   return v;
 }
 }  // namespace
 
+#ifdef VG_TUNING  // diagnostic builds: a.dbg bits 8 = no epilogue stores, 16 = no phase-2 loads, 32 = no phase-1 loads, 64 = no epilogue at all
+#define RW_DBG(bit) (a.dbg & (bit))
+#else
+#define RW_DBG(bit) 0
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING + RW_SINK + RW_GAM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wid >> 2;  // the two waves of a SIMD are w and w + 4
   const int u0 = (int)((long long)blockIdx.x * a.units / a.nwg), u1 = (int)((long long)(blockIdx.x + 1) * a.units / a.nwg);
   if (u0 >= u1) return;  // never: the launcher keeps nwg <= units
   const int nsteps = a.K >> 5;
-  const int g = lane >> 4, li = lane & 15;
   const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
-  // fragment addresses inside a stage: W rows 48 wid + 16 nt + li, A rows 16 mt + li; the swizzle only sees li
-  const unsigned fsw = (unsigned)((g ^ rw_row_f(li)) << 4);
-  const unsigned fw = sbase + (unsigned)((48 * wid + li) * 64) + fsw;     // n-tile nt at + 1024 nt
-  const unsigned fa = sbase + (unsigned)(RW_WIMG + li * 64) + fsw;        // m-tile mt at + 1024 mt
-  // LDS-DMA lane offsets: W pieces are contiguous; an A piece is 16 rows x 64 B, position lane&3 of row lane>>2 holds
-  // chunk (lane&3) ^ f(row)
-  const unsigned offW = (unsigned)lane * 16u;
-  const unsigned offA = ((unsigned)(lane >> 2) * (unsigned)a.lda + (unsigned)(((lane & 3) ^ rw_row_f(lane >> 2)) << 3)) * 2u;
   const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
 
+  if (EPI == VG_ROW_LNBWD && tid < RW_E / 4)  // visible to everyone behind the first tile's barriers
+    *(f32x4*)(smem + RW_RING + RW_SINK + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
   float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
 
   auto tile = [&](auto mt_c, const int m0) {
     constexpr int MT = decltype(mt_c)::value;
+    // lane-derived addresses are recomputed per tile from an opaque copy of the lane id: carried across the tile loop their
+    // live ranges would span the epilogue, and the allocator spills them INTO the k loop (a reload there drains the DMA ring)
+    int lnm = lane;
+    asm volatile("" : "+v"(lnm));
+    // fragment addresses inside a stage: W rows 48 wid + 16 nt + li, A rows 16 mt + li; the swizzle only sees li
+    const unsigned fsw = (unsigned)((((lnm >> 4) ^ rw_row_f(lnm & 15))) << 4);
+    const unsigned fw = sbase + (unsigned)((48 * wid + (lnm & 15)) * 64) + fsw;     // n-tile nt at + 1024 nt
+    const unsigned fa = sbase + (unsigned)(RW_WIMG + (lnm & 15) * 64) + fsw;        // m-tile mt at + 1024 mt
+    // LDS-DMA lane offsets: W pieces are contiguous; an A piece is 16 rows x 64 B, position lane&3 of row lane>>2 holds
+    // chunk (lane&3) ^ f(row)
+    const unsigned offW = (unsigned)lnm * 16u;
+    const unsigned offA = ((unsigned)(lnm >> 2) * (unsigned)a.lda + (unsigned)(((lnm & 3) ^ rw_row_f(lnm >> 2)) << 3)) * 2u;
     const int pps = 3 + (wid < MT ? 1 : 0) + ((MT == 9 && wid == 0) ? 1 : 0);  // LDS-DMA pieces of this wave per stage
     const char* wptr = (const char*)a.Wp + 1024 * wid;
     const char* aptr = (const char*)a.A + ((long long)(m0 + 16 * wid) * a.lda) * 2;
     auto issue = [&](int slot) {
       asm volatile("" : "+s"(wptr), "+s"(aptr));
       unsigned char* d = smem + slot * RW_STAGE + 1024 * wid;
-      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + offW), (lptr_t)d, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + 8192 + offW), (lptr_t)(d + 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wptr + 16384 + offW), (lptr_t)(d + 16384), 16, 0, 0);
-      if (wid < MT) __builtin_amdgcn_global_load_lds((gptr_t)(aptr + offA), (lptr_t)(d + RW_WIMG), 16, 0, 0);
-      if (MT == 9 && wid == 0) __builtin_amdgcn_global_load_lds((gptr_t)(aptr + a8 + offA), (lptr_t)(d + RW_WIMG + 8192), 16, 0, 0);
+#ifdef VG_TUNING  // diagnostic builds (make var SRC=gemm_row): a.dbg bit 2 = W pieces re-read stage 0, bit 4 = A pieces re-read stage 0
+      const char* wsrc = (a.dbg & 2) ? (const char*)a.Wp + 1024 * wid : wptr;
+      const char* asrc = (a.dbg & 4) ? (const char*)a.A + ((long long)(m0 + 16 * wid) * a.lda) * 2 : aptr;
+#else
+      const char* wsrc = wptr; const char* asrc = aptr;
+#endif
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + offW), (lptr_t)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 8192 + offW), (lptr_t)(d + 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 16384 + offW), (lptr_t)(d + 16384), 16, 0, 0);
+      if (wid < MT) __builtin_amdgcn_global_load_lds((gptr_t)(asrc + offA), (lptr_t)(d + RW_WIMG), 16, 0, 0);
+      if (MT == 9 && wid == 0) __builtin_amdgcn_global_load_lds((gptr_t)(asrc + a8 + offA), (lptr_t)(d + RW_WIMG + 8192), 16, 0, 0);
       wptr += RW_WIMG; aptr += 64;
+    };
+    // Epilogue-operand prefetch: the rows of res (LNFWD) / x and gres (LNBWD) this tile's epilogue will read are ONE contiguous
+    // block of 12 MT KiB per tensor.  Each wave streams one 1-KiB piece of it per tensor and stage into a sink behind the ring,
+    // so the lines are in L2 / Infinity Cache when the epilogue asks for them - its loads were half of an epilogue that runs with
+    // the MFMA pipe idle.  The pieces sit in the same in-order vmcnt queue as the ring's: the counted waits below include them.
+    constexpr int PF = (EPI == VG_ROW_LNFWD) ? 1 : 2;
+    constexpr int NPIECE = 12 * MT, PFJ = (NPIECE + 7) / 8;
+    const char* pf0 = (const char*)(EPI == VG_ROW_LNFWD ? a.res : a.x);
+    const char* pf1 = (const char*)(EPI == VG_ROW_LNFWD ? nullptr : (a.gres ? a.gres : a.x));
+    const int pfj = pf0 ? PFJ : 0;  // stages that carry prefetch pieces
+    auto pf_ops = [&](int k) { return (k >= 0 && k < pfj) ? PF : 0; };
+    auto prefetch = [&](int j) {
+      const int q = min(8 * j + wid, NPIECE - 1);
+      const long long off = (long long)m0 * (RW_E * 2) + 1024 * q;
+      const char* s0 = pf0 + off;
+      asm volatile("" : "+s"(s0));
+      __builtin_amdgcn_global_load_lds((gptr_t)(s0 + offW), (lptr_t)(smem + RW_RING + 1024 * wid), 16, 0, 0);
+      if (PF == 2) {
+        const char* s1 = pf1 + off;
+        asm volatile("" : "+s"(s1));
+        __builtin_amdgcn_global_load_lds((gptr_t)(s1 + offW), (lptr_t)(smem + RW_RING + 1024 * wid), 16, 0, 0);
+      }
     };
     struct Frags { u32x4 w[3]; u32x4 m[MT]; };
     auto read_frags = [&](Frags& f, int slot) {
@@ -130,12 +191,15 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     // stage s-1 left; fragment reads of stage s+1 into the other register set; this stage's MFMAs.
     auto stage = [&](Frags& cur, Frags& nxt, int s) {
       if (s + 1 < nsteps) {
-        if (s + 2 < nsteps) rw_wait_vm(pps); else rw_wait_vm(0);
+        // my pieces of stage s+1 (issued in stage s-2, or by the prologue) have landed; younger than them, and free to still
+        // be in flight: the prefetch pieces of stages s-2 and s-1 and the pieces of stage s+2
+        if (s + 2 < nsteps) rw_wait_vm(pps + pf_ops(s - 2) + pf_ops(s - 1)); else rw_wait_vm(0);
         asm volatile("s_barrier" ::: "memory");
       }
       wait_frags(cur);  // requested a stage ago
       if (half == 0) {
         if (s + 3 < nsteps) issue((s + 3) & 3);
+        if (s < pfj) prefetch(s);
         if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -155,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       __builtin_amdgcn_sched_barrier(0);
       if (half != 0) {
         if (s + 3 < nsteps) issue((s + 3) & 3);
+        if (s < pfj) prefetch(s);
         if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
       }
     };
@@ -166,42 +231,145 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     // every wave has its last fragments in registers (lgkmcnt(0) above) and no DMA is in flight: the ring is free
     asm volatile("s_barrier" ::: "memory");
 
-    // ================================ epilogue, phase 1: accumulators -> bf16 tile in LDS ================================
-    // a lane holds C[m = 16 mt + li][n = 48 wid + 16 nt + 4 g + r], r = 0..3
+    if (RW_DBG(64)) { if (acc[0][0][0] == 12345.f) a.Y[0] = (bf16)1.f; return; }
+    // ======================================================= epilogue =======================================================
+    // Phase 1: a lane holds C[m = 16 mt + li][n = 48 wid + 16 nt + 4 g + r], r = 0..3, and writes it to a tile in LDS (the ring
+    // is free).  Phase 2: the tile is re-read row-wise, 16 lanes per row (norm.hip's layout: lane `sub` owns the 16-byte chunks
+    // sub, sub + 16, sub + 32; wave w takes rows 32 ps + 4 w + rg of pass ps), so every global access is a whole row in 16-byte
+    // pieces.  With two waves per SIMD nothing hides a load's latency: the global loads of pass ps+1 are issued before pass ps is
+    // computed (those of pass 0 before phase 1), and the row sums go over DPP rotations, not the LDS crossbar.
+    // Everything the epilogue reads through is made opaque HERE: otherwise the loads of gamma / beta / bias (invariant over
+    // the tiles of a workgroup) are hoisted above the k loop, stay live across it, and the main loop - at 250 registers on its
+    // own - spills a fragment address and reloads it behind a vmcnt(0) every stage, draining the DMA ring.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int sub = ln & 15, rg = ln >> 4, g = ln >> 4, li = ln & 15;
+    VgRowArgs e = a;
+    asm volatile("" : "+s"(e.bias), "+s"(e.res), "+s"(e.Y), "+s"(e.Yn), "+s"(e.mean_out), "+s"(e.rstd_out), "+s"(e.beta), "+s"(e.gamma));
+    asm volatile("" : "+s"(e.x), "+s"(e.mean), "+s"(e.rstd), "+s"(e.gres), "+s"(e.dx), "+s"(e.dxm));
     if (EPI == VG_ROW_LNFWD) {
+      // LNFWD keeps the sum in fp32 until the residual is added (ONE rounding, as the unfused epilogue had): fp32 tile rows of
+      // 1552 B, 5 m-tiles (80 rows) at a time
+      constexpr int HM = 5, NH = (MT + HM - 1) / HM;
       const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
       const float dscale = a.drop_scale;
       f32x4 b4[3];
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
         b4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.bias) b4[nt] = *(const f32x4*)(a.bias + 48 * wid + 16 * nt + 4 * g);
+        if (e.bias) b4[nt] = *(const f32x4*)(e.bias + 48 * wid + 16 * nt + 4 * g);
       }
-      bf16x4 rr[3][MT];
+      float gam[3][8], bet[3][8];
+      if (e.Yn) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int i = 0; i < 3; ++i) {
+          const int c = 8 * (sub + 16 * i);
+          const f32x4 g0 = *(const f32x4*)(e.gamma + c), g1 = *(const f32x4*)(e.gamma + c + 4);
+          const f32x4 b0 = *(const f32x4*)(e.beta + c), b1 = *(const f32x4*)(e.beta + c + 4);
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-          rr[nt][mt] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-          if (a.res) rr[nt][mt] = *(const bf16x4*)(a.res + (size_t)(m0 + 16 * mt + li) * RW_E + 48 * wid + 16 * nt + 4 * g);
+          for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; bet[i][j] = b0[j]; bet[i][j + 4] = b1[j]; }
         }
+      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int h = 0; h < NH; ++h) {
+        constexpr int dummy = 0; (void)dummy;
+        const int mt0 = h * HM;
+        const int hm = (MT - mt0) < HM ? (MT - mt0) : HM;  // m-tiles of this half (compile-time after unrolling)
+        const int rows = 16 * hm, passes = (rows + 31) / 32;
+        // residual rows of pass 0 (phase-2 layout): in flight across the dump
+        bf16x8 rn[3];  // residual rows of the NEXT pass
+        auto ld_res = [&](bf16x8 (&dst)[3], int ps) {
+          const int rl = 32 * ps + 4 * wid + rg;
+          const size_t row = (size_t)(m0 + 16 * mt0 + (rl < rows ? rl : 0));
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-          const int n = 48 * wid + 16 * nt + 4 * g;
-          f32x4 v = acc[nt][mt] + b4[nt];
-          if (dthr) {
-            const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * mt + li) * (unsigned)RW_E + (unsigned)n) >> 2);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= vg_drop_factor(wd, r, dthr, dscale);
+          for (int i = 0; i < 3; ++i) {
+            dst[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (e.res && !RW_DBG(32)) dst[i] = *(const bf16x8*)(e.res + row * RW_E + 8 * (sub + 16 * i));
           }
-          bf16x4 o;
+        };
+        ld_res(rn, 0);
+        if (h > 0) __syncthreads();  // the previous half's rows have been read
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r] + vg_bf2f(rr[nt][mt][r]));
-          *(bf16x4*)(smem + (16 * mt + li) * RW_TS + n * 2) = o;
+        for (int mt = 0; mt < HM; ++mt) {
+          if (mt0 + mt < MT) {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+              const int n = 48 * wid + 16 * nt + 4 * g;
+              f32x4 v = acc[nt][mt0 + mt < MT ? mt0 + mt : 0] + b4[nt];
+              if (dthr) {
+                const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * (mt0 + mt) + li) * (unsigned)RW_E + (unsigned)n) >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= vg_drop_factor(wd, r, dthr, dscale);
+              }
+              *(f32x4*)(smem + (16 * mt + li) * RW_TSF + n * 4) = v;
+            }
+          }
         }
+        __syncthreads();
+#pragma unroll 1
+        for (int ps = 0; ps < passes; ++ps) {
+          {
+            const int rem = rows - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
+            bf16x8 rc[3] = {rn[0], rn[1], rn[2]};
+            if (ps + 1 < passes) ld_res(rn, ps + 1);
+            if (rem >= 32 || wid < 4) {
+              const int rl = 32 * ps + 4 * wid + rg;
+              const size_t row = (size_t)(m0 + 16 * mt0 + rl);
+              float v[3][8];
+              float sm = 0.f;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                const f32x4 t0 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i));
+                const f32x4 t1 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i) + 16);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  o[j] = vg_f2bf(t0[j] + vg_bf2f(rc[i][j]));
+                  o[j + 4] = vg_f2bf(t1[j] + vg_bf2f(rc[i][j + 4]));
+                }
+                if (!RW_DBG(8)) *(bf16x8*)(e.Y + row * RW_E + 8 * (sub + 16 * i)) = o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[i][j] = vg_bf2f(o[j]); sm += v[i][j]; }
+              }
+              if (e.Yn) {
+                const float mu = rw_row16_sum(sm) * (1.0f / RW_E);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mu; q += c * c; }  // unfused, as norm.hip's build has it
+                const float rs = rsqrtf(fmaf(rw_row16_sum(q), 1.0f / RW_E, a.eps));  // norm.hip's contracted form: bit-identical statistics
+                if (sub == 0) { e.mean_out[row] = mu; e.rstd_out[row] = rs; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  bf16x8 o;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(fmaf((v[i][j] - mu) * rs, gam[i][j], bet[i][j]));
+                  if (!RW_DBG(8)) *(bf16x8*)(e.Yn + row * RW_E + 8 * (sub + 16 * i)) = o;
+                }
+              }
+            }
+          }
+        }
+      }
     } else {
+      constexpr int ROWS = 16 * MT, PASSES = (ROWS + 31) / 32;
+      const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
+      const float dscale = a.drop_scale;
+      // operands of pass 0 in flight across the dump
+      bf16x8 xn[3];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
+      float mun, rsn;
+      auto ld_ops = [&](int ps) {
+        const int rl = 32 * ps + 4 * wid + rg;
+        const size_t row = (size_t)(m0 + (rl < ROWS ? rl : 0));
+        mun = e.mean[row]; rsn = e.rstd[row];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          xn[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+          if (!RW_DBG(16)) xn[i] = *(const bf16x8*)(e.x + row * RW_E + 8 * (sub + 16 * i));
+        }
+      };
+      ld_ops(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -212,123 +380,66 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r]);
           *(bf16x4*)(smem + (16 * mt + li) * RW_TS + (48 * wid + 16 * nt + 4 * g) * 2) = o;
         }
-    }
-    __syncthreads();
-
-    // ================================ phase 2: row-wise, 16 lanes per row (norm.hip's layout) ===========================
-    // lane `sub` of a row owns the 16-byte chunks sub, sub + 16, sub + 32; wave w takes rows 4 (8 i + w) + rg
-    const int sub = lane & 15, rg = lane >> 4;
-    constexpr int ROWS = 16 * MT, PASSES = (ROWS + 31) / 32;
-    if (EPI == VG_ROW_LNFWD) {
-      float gam[3][8], bet[3][8];
-      if (a.Yn) {
+      __syncthreads();
+      float ag[3][8], ab[3][8], ac[3][8];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int c = 8 * (sub + 16 * i);
-          const f32x4 g0 = *(const f32x4*)(a.gamma + c), g1 = *(const f32x4*)(a.gamma + c + 4);
-          const f32x4 b0 = *(const f32x4*)(a.beta + c), b1 = *(const f32x4*)(a.beta + c + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; bet[i][j] = b0[j]; bet[i][j + 4] = b1[j]; }
-        }
-      }
-#pragma unroll 1
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int rl = 4 * (8 * ps + wid) + rg;
-        const bool ok = rl < ROWS;
-        const int rc = ok ? rl : 0;
-        const size_t row = (size_t)(m0 + rc);
-        float v[3][8];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const bf16x8 t = *(const bf16x8*)(smem + rc * RW_TS + 16 * (sub + 16 * i));
-          if (ok) *(bf16x8*)(a.Y + row * RW_E + 8 * (sub + 16 * i)) = t;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { v[i][j] = vg_bf2f(t[j]); s += v[i][j]; }
-        }
-        if (!a.Yn) continue;
-        const float mu = rw_row16_sum(s) * (1.0f / RW_E);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mu; q += c * c; }
-        const float rs = rsqrtf(rw_row16_sum(q) * (1.0f / RW_E) + a.eps);
-        if (!ok) continue;
-        if (sub == 0) { a.mean_out[row] = mu; a.rstd_out[row] = rs; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = vg_f2bf((v[i][j] - mu) * rs * gam[i][j] + bet[i][j]);
-          *(bf16x8*)(a.Yn + row * RW_E + 8 * (sub + 16 * i)) = o;
-        }
-      }
-    } else {
-      const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
-      const float dscale = a.drop_scale;
-      float gam[3][8], ag[3][8], ab[3][8], ac[3][8];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int c = 8 * (sub + 16 * i);
-        const f32x4 g0 = *(const f32x4*)(a.gamma + c), g1 = *(const f32x4*)(a.gamma + c + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; }
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
-      }
+      const unsigned char* gam_lds = smem + RW_RING + RW_SINK;
 #pragma unroll 1
       for (int ps = 0; ps < PASSES; ++ps) {
-        const int rl = 4 * (8 * ps + wid) + rg;
-        const bool ok = rl < ROWS;
-        const int rc = ok ? rl : 0;
-        const size_t row = (size_t)(m0 + rc);
-        const float mu = a.mean[row], rs = a.rstd[row];
-        bf16x8 xr[3], gr[3];
+        const int rem = ROWS - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
+        bf16x8 xc[3] = {xn[0], xn[1], xn[2]};
+        const float mu = mun, rs = rsn;
+        if (ps + 1 < PASSES) ld_ops(ps + 1);
+        if (rem >= 32 || wid < 4) {
+          const int rl = 32 * ps + 4 * wid + rg;
+          const size_t row = (size_t)(m0 + rl);
+          bf16x8 gr[3];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          xr[i] = *(const bf16x8*)(a.x + row * RW_E + 8 * (sub + 16 * i));
-          gr[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-          if (a.gres) gr[i] = *(const bf16x8*)(a.gres + row * RW_E + 8 * (sub + 16 * i));
-        }
-        float xh[3][8], gg[3][8];
-        float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const bf16x8 t = *(const bf16x8*)(smem + rc * RW_TS + 16 * (sub + 16 * i));
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float h = ok ? (vg_bf2f(xr[i][j]) - mu) * rs : 0.f;
-            const float d = ok ? vg_bf2f(t[j]) : 0.f;
-            xh[i][j] = h;
-            ag[i][j] += d * h;
-            ab[i][j] += d;
-            const float gv = d * gam[i][j];
-            gg[i][j] = gv;
-            c1 += gv;
-            c2 += gv * h;
+          for (int i = 0; i < 3; ++i) {
+            gr[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (e.gres && !RW_DBG(16)) gr[i] = *(const bf16x8*)(e.gres + row * RW_E + 8 * (sub + 16 * i));
           }
-        }
-        c1 = rw_row16_sum(c1) * (1.0f / RW_E);
-        c2 = rw_row16_sum(c2) * (1.0f / RW_E);
+          float xh[3][8], gg[3][8];
+          float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int c = 8 * (sub + 16 * i);
-          bf16x8 o;
+          for (int i = 0; i < 3; ++i) {
+            const bf16x8 t = *(const bf16x8*)(smem + rl * RW_TS + 16 * (sub + 16 * i));
+            const f32x4 gm0 = *(const f32x4*)(gam_lds + 32 * (sub + 16 * i)), gm1 = *(const f32x4*)(gam_lds + 32 * (sub + 16 * i) + 16);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(rs * (gg[i][j] - c1 - xh[i][j] * c2) + vg_bf2f(gr[i][j]));
-          if (ok) *(bf16x8*)(a.dx + row * RW_E + c) = o;
-          if (a.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
-            const unsigned i4 = ((unsigned)row * (unsigned)RW_E + (unsigned)c) >> 2;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const unsigned wd = vg_drop_word(dkey, i4 + q);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[4 * q + j] = vg_f2bf(vg_bf2f(o[4 * q + j]) * vg_drop_factor(wd, j, dthr, dscale));
+            for (int j = 0; j < 8; ++j) {
+              const float h = (vg_bf2f(xc[i][j]) - mu) * rs;
+              const float d = vg_bf2f(t[j]);
+              xh[i][j] = h;
+              ag[i][j] = fmaf(d, h, ag[i][j]);
+              ab[i][j] += d;
+              const float gv = d * (j < 4 ? gm0[j] : gm1[j - 4]);
+              gg[i][j] = gv;
+              c1 += gv;
+              c2 = fmaf(gv, h, c2);
             }
-            if (ok) *(bf16x8*)(a.dxm + row * RW_E + c) = o;
           }
-          if (ok) {
+          c1 = rw_row16_sum(c1) * (1.0f / RW_E);
+          c2 = rw_row16_sum(c2) * (1.0f / RW_E);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int c = 8 * (sub + 16 * i);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), vg_bf2f(gr[i][j])));
+            if (!RW_DBG(8)) *(bf16x8*)(e.dx + row * RW_E + c) = o;
+            if (e.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
+              const unsigned i4 = ((unsigned)row * (unsigned)RW_E + (unsigned)c) >> 2;
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const unsigned wd = vg_drop_word(dkey, i4 + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * q + j] = vg_f2bf(vg_bf2f(o[4 * q + j]) * vg_drop_factor(wd, j, dthr, dscale));
+              }
+              if (!RW_DBG(8)) *(bf16x8*)(e.dxm + row * RW_E + c) = o;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) ac[i][j] += vg_bf2f(o[j]);
           }
@@ -366,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   bool first = true;
 #pragma unroll 1
   while (n > 0) {
-    const int mt = n <= RW_MAXMT ? n : 8;
+    const int mt = n <= RW_MAXMT ? n : (RW_MAXMT == 9 ? 8 : (n >= 2 * RW_MAXMT ? RW_MAXMT : (n + 1) / 2));
     if (!first) __syncthreads();  // the previous tile's epilogue has finished with the ring
     switch (mt) {
       case 1: tile(std::integral_constant<int, 1>{}, m0); break;
@@ -442,6 +553,10 @@ int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
   if ((long long)a.M * RW_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
   a.units = a.M / 16;
   a.nwg = nwg;
+#ifdef VG_TUNING
+  a.dbg = getenv("VG_ROW_DBG") ? atoi(getenv("VG_ROW_DBG")) : 0;
+  if (a.dbg & 1) a.lda = 0;  // every row of A is row 0: the A stream comes from L2
+#endif
   if (epi == VG_ROW_LNFWD) {
     if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta))) return -1;
     hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD>), dim3(nwg), dim3(512), 0, st, a);

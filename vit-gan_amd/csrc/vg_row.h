@@ -12,6 +12,7 @@ struct VgRowArgs {
   const bf16* Wp;          // packed weights: [K/32][384][32] stage images (vg_pack_rows_launch)
   int M, K;                // M % 16 == 0, K % 64 == 0
   int units, nwg;          // 16-row units of A; workgroups (filled by the launcher)
+  int dbg;                 // diagnostic builds only (VG_TUNING)
   // ---- VG_ROW_LNFWD:  y = res + drop(A W^T + bias);  yn = LN(y) * gamma + beta ------------------------------------
   const float* bias;       // [384] (nullable)
   const bf16* res;         // [M, 384] (nullable)
