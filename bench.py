@@ -76,83 +76,137 @@ def gen_flops_per_image(latent, tokens, embed, layers, siren_hidden, out_feature
 
 
 PEAK_HBM_GBS = 8000.0      # HBM3E, MI355X_MICROARCH.md "Chip-level parameters" (6.3 TB/s is what a streaming copy reaches)
-TRAFFIC_FILE = "profiles/r02_gemm_pmc_traffic.json"
+TRAFFIC_FILE = "profiles/r03_gemm_pmc_traffic.json"      # tools/pmc_traffic.py over tools/gemm_bench.py (separate --pmc passes)
+STEP_PMC_FILE = "profiles/r03_step_pmc_summary.json"     # tools/pmc_summary.py over the step (separate --pmc passes)
+E = 384
 
 
-def gemm_roofline(torch, B):
-    """Dominant kernel of the step (rocprof: profiles/r02_bench_b256_kernel_stats.csv) =
-    vg_gemm_kernel<1, 4, 0, 0>, the input-gradient GEMM, timed at its heaviest shape, the QKV dgrad of the fused real+fake
-    pass: dX[M,384] = dY[M,1152] @ Wqkv[1152,384], M = 2B*65.
-
-    Duration = PER-DISPATCH time: every launch sits between its own pair of HIP events on the stream the kernel runs on
-    (an event completes only when the launch before it has finished, so consecutive launches do not overlap inside a pair:
-    this is what rocprofv3's per-dispatch AverageNs measures; profiles/r02_roofline_gemm_kernel_stats.csv is the same
-    command under the profiler).  The back-to-back figure (one event pair around all launches, ramp-down of one launch
-    under the ramp-up of the next) is reported beside it.
-
-    Bound: the shape's algorithmic intensity, 2MNK / 2(MN + NK + MK) = 285 flop/B, is just under the chip's ridge
-    (2500 TFLOP/s / 8 TB/s = 312 flop/B): by the roofline model it is HBM-bound, narrowly, and `frac` is taken against
-    the 8 TB/s HBM peak; the fraction of the dense bf16 MFMA peak is reported too (`mfma`).  What actually limits the
-    kernel is neither roof but the L2->LDS staging rate.
-    `traffic` = HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gfx950
-    FETCH_SIZE x2 correction), read from the committed summary named in `traffic_source` - PMC counters cannot be read
-    from inside the process."""
-    import ctypes as C
-    from vit_gan_amd import _lib
-    M, N, K = 2 * B * 65, 1152, 384  # dY [M,N], W [N,K], dX [M,K]
-    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)
-    w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
-    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    L = _lib.lib()
-
-    def run():
-        _lib.check(L.vg_linear_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, N, K, 0, None, None, 0.0, st), "vg_linear_dgrad")
-    for _ in range(5):
-        run()
-    reps = 50
+def _per_dispatch_us(torch, fn, reps):
+    """PER-DISPATCH time: every launch sits between its own pair of HIP events on the stream the kernel runs on (an event
+    completes only when the launch before it has finished, so consecutive launches do not overlap inside a pair: this is what
+    rocprofv3's per-dispatch AverageNs measures).  Returns (mean, median, min) in microseconds."""
+    for _ in range(3):
+        fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     torch.cuda.synchronize()
-    for e0, e1 in ev:       # per-dispatch: one event pair per launch
+    for e0, e1 in ev:
         e0.record()
-        run()
+        fn()
         e1.record()
     torch.cuda.synchronize()
-    per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-    ms = sum(per) / reps
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()             # back-to-back: one pair around all launches
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms_b2b = e0.elapsed_time(e1) / reps
-    flops = 2.0 * M * N * K
-    byts = 2 * (M * N + N * K + M * K)
-    tf = flops / (ms * 1e-3) / 1e12
-    gbs = byts / (ms * 1e-3) / 1e9
-    traffic, source = None, None
+    t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+    return sum(t) / len(t), t[len(t) // 2], t[0]
+
+
+def step_roofline(torch, B, reps=30):
+    """Roofline of the step's heaviest kernels, timed live at their heaviest shapes (the fused real+fake pass: M = 2B*65 rows).
+
+    Dominant kernel (rocprof: profiles/r03_bench_b256_kernel_stats.csv) = vg_gemm_row_kernel<1>, the full-row input-gradient
+    GEMM with the LayerNorm backward in its epilogue (csrc/gemm_row.hip), at the QKV shape: dx = gres + LN'(dqkv[M,1152] Wqkv),
+    dxm = dx * mask.  Algorithmic work per launch: 2*M*384*1152 flops; bytes = dqkv + packed W + x + gres + dx + dxm (bf16) +
+    mean, rstd (fp32) = 2*(M*1152 + 384*1152 + 4*M*384) + 8*M.  Intensity 163 flop/B is under the chip's ridge (2500 TFLOP/s /
+    8 TB/s = 312): by the roofline model it is HBM-bound, `frac` is taken against the 8 TB/s HBM peak and the fraction of the
+    dense bf16 MFMA peak is reported beside it.
+    `traffic` = HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gfx950
+    FETCH_SIZE x2 correction) over tools/gemm_bench.py, read from the committed summary named in `traffic_source` - PMC
+    counters cannot be read from inside the process.
+    `kernels`: the same figures for the five heaviest instantiations of the step (shape, per-dispatch time, TFLOP/s, GB/s, both
+    fractions), each through the C ABI entry point the engine uses for it."""
+    import ctypes as C
+    from vit_gan_amd import _lib
+    L = _lib.lib()
+    BF = torch.bfloat16
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    M = 2 * B * 65
+
+    def p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def rnd(*shape, s=1.0):
+        return (torch.randn(*shape, device="cuda") * s).to(BF)
+
+    def packed(w, K, tr):
+        wp = torch.empty(E * K, device="cuda", dtype=BF)
+        _lib.check(L.vg_row_pack_weight(p(w), w.shape[1], K, tr, p(wp), st), "vg_row_pack_weight")
+        return wp
+
+    x384, x768, x1152, res = rnd(M, 384), rnd(M, 768), rnd(M, 1152), rnd(M, 384)
+    gam, bet, bias = torch.ones(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    mean, rstd = torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")
+    o384, o384b, o768, o768b, o1152 = (torch.empty(M, n, device="cuda", dtype=BF) for n in (384, 384, 768, 768, 1152))
+    wqkv, w1, w2 = rnd(1152, 384, s=0.05), rnd(768, 384, s=0.05), rnd(384, 768, s=0.05)
+    wqkv_t, w2_p = packed(wqkv, 1152, 1), packed(w2, 768, 0)
+    b768 = torch.zeros(768, device="cuda")
+    part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
+    lse = torch.zeros(2 * B * 4 * 65, device="cuda")
+    dw = torch.zeros(1152, 384, device="cuda")
+    slab = torch.empty(4 * 1152 * 384, device="cuda")
+    S, H, HE = 65, 4, 96
+
+    def chk(rc, what):
+        _lib.check(rc, what)
+
+    specs = [
+        ("vg_gemm_row_kernel<1>: QKV input gradient + LayerNorm backward (dx, dxm)", [M, 384, 1152],
+         lambda: chk(L.vg_linear_dgrad_ln_bwd(p(x1152), p(wqkv_t), p(x384), p(mean), p(rstd), p(gam), p(res), p(o384), p(o384b), p(part), M, 1152,
+                                              0.1, 1, 0, None, st), "vg_linear_dgrad_ln_bwd"),
+         2.0 * M * 384 * 1152, 2 * (M * 1152 + 384 * 1152 + 4 * M * 384) + 8 * M, "row qkv dgrad+ln bwd"),
+        ("vg_gemm_row_kernel<0>: fc2 + dropout + residual + next LayerNorm", [M, 384, 768],
+         lambda: chk(L.vg_linear_ln_fwd(p(x768), p(w2_p), p(bias), p(res), p(o384), p(o384b), p(mean), p(rstd), p(gam), p(bet), M, 768, 1e-5,
+                                        0.1, 1, 2, None, st), "vg_linear_ln_fwd"),
+         2.0 * M * 384 * 768, 2 * (M * 768 + 384 * 768 + 3 * M * 384) + 8 * M, "row fc2+res+ln fwd"),
+        ("vg_gemm_tn384_kernel<6>: QKV weight gradient (one of the four problems of a block's grouped launch)", [1152, 384, M],
+         lambda: chk(L.vg_linear_wgrad(p(x1152), p(x384), p(dw), p(slab), slab.numel(), M, 1152, 384, 4, 1, st), "vg_linear_wgrad"),
+         2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384) + 4 * 4 * 1152 * 384, "tn qkv wgrad"),
+        ("vg_attn_bwd_kernel<96,5>: fused attention backward, one workgroup per (image, head)", [2 * B, H, S, HE],
+         lambda: chk(L.vg_attention_bwd(p(x1152), p(x384), p(res), p(lse), p(o1152), 2 * B, H, S, HE, 1.0 / HE ** 0.5, st), "vg_attention_bwd"),
+         10.0 * 2 * B * H * S * S * HE, 2 * (M * 1152 * 2 + M * 384 * 2) + 4 * 2 * B * H * S, None),
+        ("vg_gemm_wr_kernel<0,1,2>: fc1 + GELU, second output for the backward", [M, 768, 384],
+         lambda: chk(L.vg_linear_fwd(p(x384), p(w1), p(b768), None, p(o768), p(o768b), None, M, 768, 384, 1, 0.0, st), "vg_linear_fwd"),
+         2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + 2 * M * 768), "wr fc1+gelu+2nd out"),
+    ]
+    traffic = {}
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
-            rec = json.load(f)["kernels"]["NN qkv dgrad"]
-        if rec["out_rows_cols_reduction"] == [M, K, N]:
-            traffic, source = rec["hbm_bytes_per_launch"], TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_bench.py)"
+            traffic = json.load(f)["kernels"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-            "traffic": traffic, "traffic_source": source,
-            "mfma": {"achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)},
-            "intensity_flop_per_byte": round(flops / byts, 1), "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
-            "kernel": "vg_gemm_kernel<1, 4, 0, 0> = NN input-gradient GEMM, 256x128 tile (QKV dgrad shape)", "shape_M_N_K": [M, K, N],
-            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
-            "avg_launch_us": round(ms * 1e3, 2), "median_launch_us": round(per[reps // 2] * 1e3, 2), "min_launch_us": round(per[0] * 1e3, 2),
-            "back_to_back_us": round(ms_b2b * 1e3, 2), "timing": "per-dispatch HIP event pairs on the kernel's stream, 50 launches"}
+    kernels = []
+    for name, shape, fn, flops, byts, tkey in specs:
+        mean_us, med_us, min_us = _per_dispatch_us(torch, fn, reps)
+        tf, gbs = flops / mean_us / 1e6, byts / mean_us / 1e3
+        rec = traffic.get(tkey) if tkey else None
+        kernels.append({"kernel": name, "shape": shape, "avg_launch_us": round(mean_us, 2), "median_launch_us": round(med_us, 2),
+                        "min_launch_us": round(min_us, 2), "tflops": round(tf, 1), "gbs": round(gbs, 1),
+                        "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+                        "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+                        "traffic": rec["hbm_bytes_per_launch"] if rec and rec.get("rows_M") == M else None})
+    d = kernels[0]
+    out = {"bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["frac_hbm"],
+           "traffic": d["traffic"],
+           "traffic_source": (TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_bench.py)") if d["traffic"] else None,
+           "mfma": {"achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": d["frac_mfma"]},
+           "intensity_flop_per_byte": round(d["algorithmic_flops_per_launch"] / d["algorithmic_bytes_per_launch"], 1),
+           "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+           "kernel": d["kernel"], "shape_M_N_K": d["shape"],
+           "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+           "avg_launch_us": d["avg_launch_us"], "median_launch_us": d["median_launch_us"], "min_launch_us": d["min_launch_us"],
+           "timing": f"per-dispatch HIP event pairs on the kernel's stream, {reps} launches", "kernels": kernels}
+    try:
+        with open(os.path.join(ROOT, STEP_PMC_FILE)) as f:
+            sp = json.load(f)
+        out["hbm_GB_per_step"] = sp["hbm"]["total_GB_per_step"]
+        out["mfma_util_percent_step"] = sp["mfma_util_percent"]["<whole step, all vg_ kernels>"]["util"]
+        out["step_pmc_source"] = STEP_PMC_FILE + " (rocprofv3 --pmc passes over bench.py, tools/pmc_summary.py; B = 256)"
+    except (OSError, KeyError, ValueError):
+        out["hbm_GB_per_step"] = None
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 256 for C2, 128 for C4 / C5)")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -163,7 +217,12 @@ def main():
                          "c4: 64x64 patch 8 E=512 8 heads; c5: 128x128 patch 16 E=768 12 heads (bf16 attention) - "
                          "both with the patch-grid generator (SURVEY 8f f1); extra measurements, not the headline")
     ap.add_argument("--loss", default="ns", choices=["ns", "hinge"])
-    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph; -1: auto (single GPU only)")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: replay the step as a hipGraph (on > 1 GPU the capture includes the RCCL all-reduces); 0: eager; -1 (default): "
+                         "on - the engine falls back to eager, loudly, when the process group cannot be captured (gloo)")
+    ap.add_argument("--compress-mapping-grad", type=int, default=1,
+                    help="data parallel only: exchange the generator's 12.6 M-parameter mapping gradient as bf16 (halves the one exchange "
+                         "that cannot hide behind compute); the engine's own default is the exact fp32 all-reduce")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--fp8-attention", type=int, default=-1,
@@ -188,7 +247,7 @@ def main():
         import vit_gan_amd  # noqa: F401
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
-        print(json.dumps({"roofline": gemm_roofline(torch, args.batch or 256)}))
+        print(json.dumps({"roofline": step_roofline(torch, args.batch or 256)}))
         return
 
     import torch
@@ -238,9 +297,10 @@ def main():
     else:
         G = SirenGenerator(image_size=IMG, embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
                            dropout=0.2 if args.dropout else 0.0).to(dev).train()
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = True if args.graph < 0 else bool(args.graph)
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
-                    concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1)
+                    concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
+                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
@@ -251,12 +311,20 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # EXACTLY args.steps steps between the barriers; events at the boundaries of (up to) 6 equal windows inside that region
+    # give the spread of the headline (device time per window, this rank)
+    nwin = max(1, min(6, args.steps // 5)) if args.steps >= 10 else 1
+    bounds = [round(k * args.steps / nwin) for k in range(nwin + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(nwin + 1)]
+    e0, e1 = marks[0], marks[-1]
     t0 = time.perf_counter()
-    e0.record()
+    marks[0].record()
+    nb = 1
     for i in range(args.steps):
         losses = eng.step(reals[i % 4])
-    e1.record()
+        if i + 1 == bounds[nb]:
+            marks[nb].record()
+            nb += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -267,6 +335,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    win = sorted(marks[k].elapsed_time(marks[k + 1]) / (bounds[k + 1] - bounds[k]) for k in range(nwin))
     lv = losses.cpu().tolist()
     ok = all(x == x and abs(x) < 1e4 for x in lv)
 
@@ -278,12 +347,14 @@ def main():
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
         # the roofline leg always times the C2 shape
-        roof = {"skipped": "--no-roofline"} if args.no_roofline else gemm_roofline(torch, 256 if args.workload != "c2" else B)
+        roof = {"skipped": "--no-roofline"} if args.no_roofline else step_roofline(torch, 256 if args.workload != "c2" else B)
         roof["step_tflops_per_gpu"] = round(step_tf, 1)
         roof["step_frac_of_peak"] = round(step_tf / PEAK_BF16_TFLOPS, 4)
         out = {
             "metric": "images/sec (G+D step) ViTGAN 32x32 patch4 dim384" if args.workload == "c2" else f"images/sec (G+D step) ViTGAN {args.workload} shape", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "windows_ms_per_step": {"n": nwin, "steps_each": args.steps // nwin, "median": round(win[nwin // 2], 4), "min": round(win[0], 4),
+                                    "max": round(win[-1], 4), "note": "device time of equal windows inside the timed region (rank 0)"},
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": {"c2": "C2: CIFAR-10-shaped 3x32x32, patch 4 (65 tokens), E=384, 4 heads, 6 blocks ViT discriminator + "
                                           "SLN/SIREN generator (z=1024, 32 tokens, 4 blocks), full alternating G+D step, AdamW",
@@ -293,7 +364,9 @@ def main():
                                           "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW"}[args.workload],
                        "fp8_attention": fp8_attn,
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
-                       "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": use_graph, "fused_real_fake_pass": not args.no_fuse,
+                       "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": eng.graph_active,
+                       "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1,
+                       "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
             "roofline": roof,
         }

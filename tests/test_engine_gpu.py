@@ -305,6 +305,18 @@ def _dp_worker(rank, world, port, out):
             torch.cuda.synchronize()
             return (D.vit._flat.flat.detach().cpu(), G._flat.flat.detach().cpu(), D.vit._flat.grad.detach().cpu(), losses.cpu(),
                     G._flat.grad.detach().cpu())
+        # hipGraph replay cannot capture a gloo exchange: the engine must say so and run eager, never silently
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            torch.manual_seed(0)
+            Dg = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, batch_size=B, transformer_blocks_count=1)).cuda().train()
+            Gg = SirenGenerator(embed=128, layers=1, siren_hidden=256).cuda().train()
+            eg = GanEngine(Dg, Gg, batch=B, use_graph=True)
+        assert not eg.graph_active and "gloo" in (eg.graph_fallback_reason or ""), eg.graph_fallback_reason
+        assert any("runs EAGER" in str(w_.message) for w_ in caught)
+        assert torch.isfinite(eg.step(torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1)).all()
+        del eg, Dg, Gg
         w, gw, gsum, losses, ggrad = run(3, False)         # D and G backward in 3 pieces, exchange overlapped
         w1, gw1, _, _, ggrad1 = run(1, False)              # one all-reduce per network after its whole backward
         w2, gw2, _, _, ggrad2 = run(3, True)               # + mapping-layer gradient exchanged as bf16
@@ -491,7 +503,34 @@ def _rccl_worker(port, out):
         torch.cuda.current_stream().wait_stream(comm)
         torch.cuda.synchronize()
         ok = torch.equal(flat.cpu(), torch.arange(4096, dtype=torch.float32)) and torch.equal(half.float().cpu(), torch.arange(1024).float().to(torch.bfloat16).float())
-        out.put(("ok", (ok, dist.get_backend())))
+        # the whole step with its (one-rank) RCCL all-reduces captured in a hipGraph: replay == eager, bit for bit, 3 steps
+        import vit_gan_amd  # noqa: F401
+        from vit_gan_amd.config import Config
+        from vit_gan_amd.engine import GanEngine
+        from vit_gan_amd.generator import SirenGenerator
+        from vit_gan_amd.modules import ViTDiscriminator
+        B = 16
+        res = []
+        for use_graph in (False, True):
+            torch.manual_seed(0)
+            D = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, batch_size=B, transformer_blocks_count=3)).cuda().train()
+            G = SirenGenerator(embed=128, layers=2, siren_hidden=256).cuda().train()
+            eng = GanEngine(D, G, batch=B, seed=4, use_graph=use_graph, external_noise=True, exchange_single_rank=True,
+                            compress_mapping_grad=True)
+            assert eng.sync.active and eng.sync.overlap
+            g = torch.Generator().manual_seed(9)
+            ls = []
+            for _ in range(3):
+                real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+                z = torch.randn(B, 1024, generator=g).cuda()
+                ls.append(eng.step(real, z).clone())
+            torch.cuda.synchronize()
+            res.append((torch.stack(ls).cpu(), D.vit._flat.flat.detach().cpu().clone(), G._flat.flat.detach().cpu().clone(),
+                        eng.graph_active, eng.graph_fallback_reason))
+            eng.close()
+        graph_ok = res[1][3] and res[1][4] is None
+        same = all(torch.equal(a, b) for a, b in zip(res[0][:3], res[1][:3]))
+        out.put(("ok", (ok and graph_ok and same, dist.get_backend(), res[1][4])))
         dist.destroy_process_group()
     except Exception as e:
         out.put(("err", f"{type(e).__name__}: {e}"))
@@ -501,7 +540,9 @@ def _rccl_worker(port, out):
 def test_rccl_backend_executes_the_exchange_calls_on_one_rank():
     """The driver's multi-GPU run uses backend "nccl" (= RCCL).  A one-GPU box cannot host two RCCL ranks, but a
     one-rank RCCL group executes the same calls - communicator creation, an asynchronous fp32 range all-reduce and a bf16
-    all-reduce on the side stream, stream joins - so that path is not first exercised on the 8-GPU node."""
+    all-reduce on the side stream, stream joins - so that path is not first exercised on the 8-GPU node.  It also runs the
+    engine's step with those collectives (staged D and G exchange, bf16 mapping gradient) CAPTURED in a hipGraph: three
+    replayed steps must equal three eager steps bit for bit (what bench.py does on more than one GPU since round 3)."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -514,4 +555,4 @@ def test_rccl_backend_executes_the_exchange_calls_on_one_rank():
     status, val = out.get(timeout=240)
     p.join(timeout=60)
     assert status == "ok", val
-    assert val[0] and val[1] == "nccl"
+    assert val[0] and val[1] == "nccl", val  # val[2]: the engine's graph fallback reason, if the capture was refused

@@ -59,7 +59,9 @@ def test_engine_errors_are_raised_not_swallowed(tmp_path, monkeypatch):
                     steps_per_epoch=1, output_base=str(tmp_path))
     runs = glob.glob(os.path.join(str(tmp_path), "output", "*"))
     assert runs and not os.path.exists(os.path.join(runs[0], "final_model.ckpt"))
-    assert "HIP engine error" in open(os.path.join(runs[0], "training.log")).read()
+    text = open(os.path.join(runs[0], "training.log")).read()
+    assert "HIP engine error" in text
+    assert "Saving the model" not in text and "NO checkpoint was written" in text  # the log must not claim a file that does not exist
 
 
 def test_exceptions_inside_the_loop_are_logged_not_raised(tmp_path):

@@ -7,7 +7,8 @@
 
 Counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream
 (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-The dispatch order of gemm_bench.py is fixed (3 warm-ups + REPS launches per shape), so shapes are recovered by position.
+The dispatch order of gemm_bench.py is fixed (3 warm-ups + REPS launches per shape, SHAPES in order), so shapes are recovered by
+position; only the GEMM kernels (vg_gemm_*) are counted - the slab folds and the weight packing are not.
 """
 import csv
 import glob
@@ -15,11 +16,12 @@ import json
 import shutil
 import sys
 
-NAMES = ["NT qkv fwd", "NT out+res", "NT fc1+gelu+pre", "NT fc2+res", "NN fc2 dgrad*gelu'", "NN fc1 dgrad", "NN qkv dgrad", "NN out dgrad",
-         "TN qkv wgrad", "TN fc1 wgrad", "TN fc2 wgrad", "TN out wgrad"]
-M = 33280
-SHAPES = [[M, 1152, 384], [M, 384, 384], [M, 768, 384], [M, 384, 768], [M, 768, 384], [M, 384, 768], [M, 384, 1152], [M, 384, 384],
-          [1152, 384, M], [768, 384, M], [384, 768, M], [384, 384, M]]
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gemm_bench  # noqa: E402  (the shape list; importing it runs nothing on the GPU)
+
+NAMES = [n for n, _, _ in gemm_bench.SHAPES]
+ALGO = {n: (f, b) for n, f, b in gemm_bench.SHAPES}
 
 
 def per_shape(d, counter):
@@ -43,11 +45,9 @@ def main():
                    "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half the bytes of a wide coalesced stream, "
                    "MI355X_MICROARCH.md section HBM); produced by tools/pmc_traffic.py", "kernels": {}}
     for i, name in enumerate(NAMES):
-        rec["kernels"][name] = {"kernel": fetch[i][0], "out_rows_cols_reduction": SHAPES[i], "FETCH_SIZE_KB": fetch[i][1],
-                                "WRITE_SIZE_KB": write[i][1], "hbm_bytes_per_launch": int((2 * fetch[i][1] + write[i][1]) * 1024)}
-        if name.startswith(("NT", "NN")):
-            m, n, k = SHAPES[i]
-            rec["kernels"][name]["algorithmic_bytes_one_output"] = 2 * (m * k + n * k + m * n)
+        rec["kernels"][name] = {"kernel": fetch[i][0], "rows_M": gemm_bench.M, "FETCH_SIZE_KB": fetch[i][1],
+                                "WRITE_SIZE_KB": write[i][1], "hbm_bytes_per_launch": int((2 * fetch[i][1] + write[i][1]) * 1024),
+                                "algorithmic_flops": ALGO[name][0], "algorithmic_bytes": ALGO[name][1]}
     json.dump(rec, open(out, "w"), indent=1)
     base = out.rsplit("_traffic.json", 1)[0]
     shutil.copy(fa, base + "_FETCH_SIZE.csv")

@@ -1,17 +1,16 @@
 #!/bin/bash
 # Produces the rocprofv3 evidence committed under profiles/ (run on the GPU box from the repo root):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # kernel stats of the default (single-stream) step and of the step with the weight gradients on a side stream, the roofline leg, PMC traffic of the GEMM shapes and the
 # whole-step MFMA-utilisation / HBM-traffic summary.  PMC passes use --kernel-trace only (no other trace domains).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() { d=$1; shift; rocprofv3 "$@" > $OUT/$d.log 2>&1; }
 prof ks_default --kernel-trace --stats --output-format csv -d $OUT/ks_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
-prof ks_side    --kernel-trace --stats --output-format csv -d $OUT/ks_side    -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --concurrent-wgrad 1
 prof ks_roof    --kernel-trace --stats --output-format csv -d $OUT/ks_roof    -- python3 $R/bench.py --roofline-only
 export REPS=3
 prof gf --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gemm_fetch -- python3 $R/tools/gemm_bench.py
@@ -23,5 +22,7 @@ prof sw --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/step_write -
 cd $R
 python3 tools/pmc_traffic.py $OUT/gemm_fetch $OUT/gemm_write $OUT/${TAG}_gemm_pmc_traffic.json > $OUT/traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/step_mfma $OUT/step_fetch $OUT/step_write $OUT/${TAG}_step_pmc_summary.json > $OUT/summary.txt 2>&1
-for n in default side roof; do f=$(find $OUT/ks_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_ks_$n.csv; done
-tail -4 $OUT/traffic.txt; tail -12 $OUT/summary.txt
+for n in default roof; do f=$(find $OUT/ks_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_ks_$n.csv; done
+python3 tools/gemm_bench.py > $OUT/${TAG}_gemm_bench.txt 2>&1
+python3 tools/row_bench.py > $OUT/${TAG}_row_bench.txt 2>&1
+tail -4 $OUT/traffic.txt; tail -12 $OUT/summary.txt; grep -v amdgpu.ids $OUT/${TAG}_gemm_bench.txt

@@ -47,11 +47,14 @@ def backward_pieces(n_layers: int, chunks: int, layer0: int, layer_stride: int, 
 
 class GradSync:
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
-                 overlap: bool = True):
+                 overlap: bool = True, single_rank: bool = False):
+        """single_rank: execute the exchange calls on a ONE-rank group too (an identity all-reduce) - how the hipGraph
+        capture of the step with its RCCL collectives is tested on a one-GPU box."""
         self.group = group
         self.world = world_size(group)
+        self.active = self.world > 1 or (bool(single_rank) and dist.is_available() and dist.is_initialized())
         self.cuda = device is not None and device.type == "cuda"
-        self.overlap = bool(overlap) and self.cuda and self.world > 1
+        self.overlap = bool(overlap) and self.cuda and self.active
         self.comm = torch.cuda.Stream(device=device) if self.overlap else None
         self._pending: List = []
 
@@ -61,7 +64,7 @@ class GradSync:
         compress: exchange a bf16 copy (half the bytes on the xGMI links; the sum is formed in bf16 by the collective and
         written back to the fp32 buffer) - used for the generator's 12.6 M-parameter mapping layer, whose gradient is
         complete only at the very end of the step and cannot be hidden behind compute."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         view = flat[lo:hi]
         if not self.overlap:

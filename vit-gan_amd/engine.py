@@ -16,6 +16,8 @@ Nothing synchronises with the host; with ``use_graph`` the whole step is replaye
 from __future__ import annotations
 
 import ctypes as C
+import warnings
+import weakref
 from typing import Optional
 
 import torch
@@ -41,7 +43,8 @@ class GanEngine:
                  concurrent_wgrad: bool = False, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
-                 two_stream: bool = False, compress_mapping_grad: bool = True, gp_weight: float = 0.0):
+                 two_stream: bool = False, compress_mapping_grad: bool = False, gp_weight: float = 0.0,
+                 exchange_single_rank: bool = False):
         """concurrent_wgrad: the discriminator's weight gradients on a side stream beside its input gradients.  Off by default
         since the persistent GEMMs (csrc/gemm_wr.hip, gemm_tn.hip: their workgroups hold the CUs for a whole launch) - the
         side stream measured 6.70 against 6.67 ms/step.
@@ -60,8 +63,15 @@ class GanEngine:
         field is missing from the reference's Config).  The penalty runs through torch autograd over the twice-
         differentiable operator set (penalty.py) on the discriminator's real / fake inputs of this step and accumulates
         into the same gradient buffer before the exchange and AdamW; not capturable in a hipGraph.
-        compress_mapping_grad (data parallel only): exchange the gradient of the generator's mapping Linear - 50 MB of
-        the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).
+        compress_mapping_grad (data parallel only, default OFF): exchange the gradient of the generator's mapping Linear - 50 MB of
+        the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).  The sum is
+        then formed in bf16 inside the collective (8 mantissa bits, error growing with the world size), so the default step is
+        the exact fp32 all-reduce and a caller that wants the halved link traffic opts in (bench.py does and says so in its line).
+        exchange_single_rank: run the staged backward and its all-reduces on a one-rank group as well (tests: the RCCL
+        collectives inside a captured step, on a box with one GPU).
+        use_graph: replay the step as one hipGraph.  On more than one rank the capture includes the RCCL all-reduces (backend
+        "nccl"); when the capture is not possible (gloo process group, a torch build that cannot capture the collective) the
+        engine says so loudly (warning + ``graph_fallback_reason``) and runs eager - it never falls back silently.
         external_noise: the latent batch is supplied by the caller (``step(real, z)``) instead of being drawn on the
         device inside the step - what parity tests use to give their CPU checker and the engine the same noise, also under
         hipGraph replay."""
@@ -89,6 +99,10 @@ class GanEngine:
         self.gp_epsilon: Optional[torch.Tensor] = None  # tests: a fixed epsilon [B,1,1,1] instead of torch.rand
         if self.gp_w != 0.0 and (use_graph or two_stream):
             raise ValueError("gp_weight: the gradient penalty runs through torch autograd and cannot be captured / forked")
+        if self.gp_w != 0.0 and bool(getattr(vit, "attention_fp8", False)):
+            # the penalty path (ops2.py) differentiates the bf16 attention kernels: with fp8 operands in the trained network
+            # it would penalise a slightly different function than the one being trained
+            raise ValueError("gp_weight: the gradient penalty is built on the bf16 attention kernels; switch attention_fp8 off")
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
@@ -96,7 +110,7 @@ class GanEngine:
         self.div_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.clip_scratch = torch.zeros(2, 1 + 1024, dtype=torch.float32, device=self.dev)  # [net][norm, partials]
         self.pg = process_group
-        self.sync = GradSync(process_group, self.dev, overlap=True)
+        self.sync = GradSync(process_group, self.dev, overlap=True, single_rank=exchange_single_rank)
         self.world = self.sync.world
         d, g = vit._dims, generator._dims
         if g.T * g.CW != d.C * d.IH * d.IH:
@@ -136,12 +150,48 @@ class GanEngine:
         self.ctx = _lib.context() if concurrent_wgrad else None
         # a load_state_dict into either network (directly or through a container such as ViTGAN) copies into the flat
         # master buffers in place: refresh the bf16 shadows the GEMMs read, or the next step runs on stale weights
-        self._hooks = [m.register_load_state_dict_post_hook(lambda _mod, _keys: self.sync_from_modules())
-                       for m in (vit, generator)]
+        # (the hook holds the engine weakly: a strong reference from the module would keep every engine ever built on it -
+        # workspaces, optimizer moments - alive, and re-run the refresh of stale engines on every later load_state_dict)
+        me = weakref.ref(self)
+
+        def _hook(_mod, _keys):
+            eng = me()
+            if eng is not None:
+                eng.sync_from_modules()
+        self._hooks = [m.register_load_state_dict_post_hook(_hook) for m in (vit, generator)]
         self.steps = 0
         self._graph = None
         self._use_graph = bool(use_graph)
+        self.graph_fallback_reason: Optional[str] = None
+        if self._use_graph and self.sync.active:
+            backend = dist.get_backend(process_group)
+            if backend != "nccl":
+                self._graph_fallback(f"process-group backend '{backend}' cannot be captured in a hipGraph (only nccl = RCCL can)")
         self._static_real = None
+
+    def _graph_fallback(self, reason: str) -> None:
+        self._use_graph = False
+        self._graph = None
+        self.graph_fallback_reason = reason
+        warnings.warn(f"GanEngine: hipGraph replay was requested but the step runs EAGER: {reason}", RuntimeWarning, stacklevel=3)
+
+    @property
+    def graph_active(self) -> bool:
+        """True when step() replays a captured hipGraph (after the first call), False in eager mode."""
+        return self._use_graph
+
+    def close(self) -> None:
+        """Detach from the modules (load_state_dict hooks) and drop the captured graph and workspaces."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
     def _nets(self):
@@ -167,7 +217,7 @@ class GanEngine:
         below it; only the last piece's exchange is exposed."""
         L = _lib.lib()
         nL = self.vit._dims.L
-        if self.world == 1 or not want_w:
+        if not self.sync.active or not want_w:
             _lib.check(L.vg_vit_backward(C.byref(nd), n_img, _p(self.ws_d), dl, dimg, want_w, st), "vg_vit_backward")
             return
         fd = self.vit._flat
@@ -183,7 +233,7 @@ class GanEngine:
         with the last kernel; its 50 MB mapping-weight part goes over the links as bf16."""
         L = _lib.lib()
         fg = self.gen._flat
-        if self.world == 1:
+        if not self.sync.active:
             _lib.check(L.vg_gen_backward(C.byref(ng), self.B, _p(self.ws_g), _p(self.dfake), st), "vg_gen_backward")
             return
         lay = flat.gen_layout(self.gen._dims)
@@ -384,9 +434,21 @@ class GanEngine:
             torch.cuda.current_stream().wait_stream(s)
             for t, keep in zip(self._state_tensors(), saved):
                 t.copy_(keep)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._enqueue(self._static_real)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self._enqueue(self._static_real)
+            except Exception as exc:  # only reachable with collectives in the step: otherwise it is all our own enqueue-only calls
+                if not self.sync.active:
+                    raise
+                torch.cuda.synchronize()
+                for t, keep in zip(self._state_tensors(), saved):  # a broken capture must not have advanced the state
+                    t.copy_(keep)
+                self.sync._pending.clear()
+                self._graph_fallback(f"capturing the step with its collectives failed: {type(exc).__name__}: {exc}")
+                self._enqueue(real)
+                return self.losses
+            self._graph = graph
         self._static_real.copy_(real)
         self._graph.replay()
         return self.losses

@@ -288,7 +288,13 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
             save_figures(dirs.save, disc_losses=disc_losses, gen_losses=gen_losses, fid_scores=fid_scores)
             torch.save(gan.state_dict(), model_path)
             save_samples(epoch, construct_noise())
-        log(f"Run took {datetime.datetime.now() - dirs.start}. Saving the model to: {model_path}")
+        took = datetime.datetime.now() - dirs.start
+        if fatal is None and save_artifacts:
+            log(f"Run took {took}. Saving the model to: {model_path}")
+        elif fatal is not None:  # the log of a failed run must not claim a checkpoint that was never written
+            log(f"Run took {took}. NO checkpoint was written: the run ended on {type(fatal).__name__}")
+        else:
+            log(f"Run took {took}.")
         _log_file = None
     if fatal is not None:
         raise fatal
