@@ -45,8 +45,7 @@ constexpr int RW_MAXMT = RW_MAXMT_;  // m-tiles per tile (tuning builds: make va
 constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
 constexpr int RW_NSLOT = 4;
 constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
-constexpr int RW_SINK = 8 * 1024;                      // behind the ring: where the operand-prefetch pieces land (never read)
-constexpr int RW_GAM = RW_E * 4;                       // behind the sink: gamma in fp32 (the LNBWD epilogue has no registers for it)
+constexpr int RW_GAM = RW_E * 4;                       // behind the ring: gamma in fp32 (the LNBWD epilogue has no registers for it)
 constexpr int RW_TS = 784;                             // row stride of the bf16 epilogue tile (LNBWD): 768 + 16 (ds_write_b64 2-way at worst)
 constexpr int RW_TSF = 1552;                           // row stride of the fp32 epilogue tile (LNFWD, 80 rows at a time): 1536 + 16
 static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
@@ -63,9 +62,7 @@ __device__ __forceinline__ void rw_wait_vm(int n) {  // n is wave-uniform (scala
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -90,7 +87,7 @@ __device__ __forceinline__ float rw_row16_sum(float v) {
 #endif
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING + RW_SINK + RW_GAM];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING + RW_GAM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wid >> 2;  // the two waves of a SIMD are w and w + 4
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
 
   if (EPI == VG_ROW_LNBWD && tid < RW_E / 4)  // visible to everyone behind the first tile's barriers
-    *(f32x4*)(smem + RW_RING + RW_SINK + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
+    *(f32x4*)(smem + RW_RING + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
   float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
 
   auto tile = [&](auto mt_c, const int m0) {
@@ -137,28 +134,6 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       if (MT == 9 && wid == 0) __builtin_amdgcn_global_load_lds((gptr_t)(asrc + a8 + offA), (lptr_t)(d + RW_WIMG + 8192), 16, 0, 0);
       wptr += RW_WIMG; aptr += 64;
     };
-    // Epilogue-operand prefetch: the rows of res (LNFWD) / x and gres (LNBWD) this tile's epilogue will read are ONE contiguous
-    // block of 12 MT KiB per tensor.  Each wave streams one 1-KiB piece of it per tensor and stage into a sink behind the ring,
-    // so the lines are in L2 / Infinity Cache when the epilogue asks for them - its loads were half of an epilogue that runs with
-    // the MFMA pipe idle.  The pieces sit in the same in-order vmcnt queue as the ring's: the counted waits below include them.
-    constexpr int PF = (EPI == VG_ROW_LNFWD) ? 1 : 2;
-    constexpr int NPIECE = 12 * MT, PFJ = (NPIECE + 7) / 8;
-    const char* pf0 = (const char*)(EPI == VG_ROW_LNFWD ? a.res : a.x);
-    const char* pf1 = (const char*)(EPI == VG_ROW_LNFWD ? nullptr : (a.gres ? a.gres : a.x));
-    const int pfj = pf0 ? PFJ : 0;  // stages that carry prefetch pieces
-    auto pf_ops = [&](int k) { return (k >= 0 && k < pfj) ? PF : 0; };
-    auto prefetch = [&](int j) {
-      const int q = min(8 * j + wid, NPIECE - 1);
-      const long long off = (long long)m0 * (RW_E * 2) + 1024 * q;
-      const char* s0 = pf0 + off;
-      asm volatile("" : "+s"(s0));
-      __builtin_amdgcn_global_load_lds((gptr_t)(s0 + offW), (lptr_t)(smem + RW_RING + 1024 * wid), 16, 0, 0);
-      if (PF == 2) {
-        const char* s1 = pf1 + off;
-        asm volatile("" : "+s"(s1));
-        __builtin_amdgcn_global_load_lds((gptr_t)(s1 + offW), (lptr_t)(smem + RW_RING + 1024 * wid), 16, 0, 0);
-      }
-    };
     struct Frags { u32x4 w[3]; u32x4 m[MT]; };
     auto read_frags = [&](Frags& f, int slot) {
       const unsigned so = (unsigned)(slot * RW_STAGE);
@@ -191,15 +166,13 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     // stage s-1 left; fragment reads of stage s+1 into the other register set; this stage's MFMAs.
     auto stage = [&](Frags& cur, Frags& nxt, int s) {
       if (s + 1 < nsteps) {
-        // my pieces of stage s+1 (issued in stage s-2, or by the prologue) have landed; younger than them, and free to still
-        // be in flight: the prefetch pieces of stages s-2 and s-1 and the pieces of stage s+2
-        if (s + 2 < nsteps) rw_wait_vm(pps + pf_ops(s - 2) + pf_ops(s - 1)); else rw_wait_vm(0);
+        // my pieces of stage s+1 have landed; those of stage s+2 may still be in flight
+        if (s + 2 < nsteps) rw_wait_vm(pps); else rw_wait_vm(0);
         asm volatile("s_barrier" ::: "memory");
       }
       wait_frags(cur);  // requested a stage ago
       if (half == 0) {
         if (s + 3 < nsteps) issue((s + 3) & 3);
-        if (s < pfj) prefetch(s);
         if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -219,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       __builtin_amdgcn_sched_barrier(0);
       if (half != 0) {
         if (s + 3 < nsteps) issue((s + 3) & 3);
-        if (s < pfj) prefetch(s);
         if (s + 1 < nsteps) read_frags(nxt, (s + 1) & 3);
       }
     };
@@ -386,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
-      const unsigned char* gam_lds = smem + RW_RING + RW_SINK;
+      const unsigned char* gam_lds = smem + RW_RING;
 #pragma unroll 1
       for (int ps = 0; ps < PASSES; ++ps) {
         const int rem = ROWS - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
