@@ -99,6 +99,23 @@ int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const
                            const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
                            float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
 
+/* The same two kernels with the v1 generator's self-modulated LayerNorm (src/v1/spectral_layer_norm.py:19-20) in the epilogue:
+ * vg_linear_sln_fwd:  Y = (res | resf[row % res_period]) + drop(A Wp^T + bias);  Yn = w * (gs * (LN(Y) * lw + lb) + bs)
+ *   replaces output_linear / the block MLP + dropout + residual + the SLN that reads the sum (src/v1/transformer.py:85-88);
+ *   resf: fp32 [res_period, 384] residual broadcast over the batch (block 0: the learned embedding, generator.py:62), or NULL.
+ * vg_linear_dgrad_sln_bwd:  dh = gres + LN'(dy_eff), dy_eff = (dY Wp) * w * gs;  dhm = dh * mask(site) (NULL: none);
+ *   dw_acc (+)= (dY Wp) * (gs * (xhat * lw + lb) + bs)  (fp32 [M,384]);  part: fp32 [vg_row_parts(M)][3*384 + 64]:
+ *   d lw | d lb | colsum(dhm ? dhm : dh) | d gs, d bs;  h_bcast_rows > 0: h has that many rows, broadcast over the batch. */
+int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
+                      void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
+                      const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,
+                      int site, const unsigned* step_dev, void* stream);
+int vg_linear_dgrad_sln_bwd(const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
+                            const float* mean, const float* rstd, const float* lw, const float* lb, const float* gs,
+                            const float* bs, const void* gres, void* dh, void* dhm, float* dw_acc, int dw_accumulate,
+                            float* part, int M, int K, float drop_p, unsigned long long seed, int site,
+                            const unsigned* step_dev, void* stream);
+
 /* dst_k[c] (+)= sum_r part[r][off_k + c] for up to 4 consecutive column segments (NULL = skip). */
 int vg_colsum_f32(const float* part, int rows, int width, float* d0, int n0, float* d1, int n1,
                   float* d2, int n2, float* d3, int n3, int accumulate, void* stream);

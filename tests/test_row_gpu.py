@@ -239,3 +239,94 @@ def test_fused_forward_is_bit_identical_to_the_unfused_pair(M, K):
     u.call("vg_layernorm_fwd", u.ptr(Y2), E, u.ptr(gam), u.ptr(bet), u.ptr(Yn2), E, u.ptr(mean2), u.ptr(rstd2), M, E, 1e-5, u.stream())
     u.sync()
     assert torch.equal(Y, Y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(Yn, Yn2)
+
+
+# ---- the same kernels with the v1 generator's self-modulated LayerNorm (src/v1/spectral_layer_norm.py:19-20) in the epilogue ----
+SLN_SHAPES = [(64, 384), (96, 768), (1024, 384), (2048, 1152), (8192, 384), (8192, 1152)]
+
+
+@pytest.mark.parametrize("M,K", SLN_SHAPES)
+@pytest.mark.parametrize("table", [False, True])
+def test_linear_sln_fwd(M, K, table):
+    u = _u()
+    T = 32
+    g = torch.Generator().manual_seed(M + K + int(table))
+    A = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(E, K, generator=g) / math.sqrt(K))
+    b = torch.randn(E, generator=g) * 0.1
+    R = u.rbf(torch.randn(M, E, generator=g))
+    tab = torch.randn(T, E, generator=g)
+    wmod = u.rbf(torch.randn(M, E, generator=g))
+    lw, lb = 1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    sc = torch.tensor([0.7, -0.3])
+    drop, seed, site = 0.2, 5, 101
+    y = (A @ W.t() + b) * _mask(u, M, drop, seed, site)
+    y = u.rbf(y + (tab.repeat(M // T, 1) if table else R))
+    ln = F.layer_norm(y, (E,), lw, lb, 1e-5)
+    yn = wmod * (sc[0] * ln + sc[1])
+    Wp = _pack(u, W, K, False)
+    dA, db, dR, dtab, dwm, dlw, dlb, dsc = u.dev(A, u.BF), u.dev(b), u.dev(R, u.BF), u.dev(tab), u.dev(wmod, u.BF), u.dev(lw), u.dev(lb), u.dev(sc)
+    Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
+    mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+    u.call("vg_linear_sln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), None if table else u.ptr(dR), u.ptr(dtab) if table else None, T, u.ptr(Y), u.ptr(Yn),
+           u.ptr(mean), u.ptr(rstd), u.ptr(dwm), u.ptr(dlw), u.ptr(dlb), u.ptr(dsc), C.c_void_p(dsc.data_ptr() + 4), M, K, 1e-5, drop, seed, site, None, u.stream())
+    u.sync()
+    u.assert_close(Y, y, BF_TOL, "Y")
+    yk = Y.float().cpu()
+    u.assert_close(Yn, wmod * (sc[0] * F.layer_norm(yk, (E,), lw, lb, 1e-5) + sc[1]), BF_TOL, "Yn vs SLN(own Y)")
+    u.assert_close(mean, yk.mean(1), 3e-5, "mean", floor=1e-6)
+    u.assert_close(rstd, 1.0 / torch.sqrt(yk.var(1, unbiased=False) + 1e-5), 3e-5, "rstd")
+    u.assert_close(Yn, yn, 2.0 ** -5, "Yn vs reference")
+
+
+@pytest.mark.parametrize("M,K", SLN_SHAPES)
+@pytest.mark.parametrize("bcast,acc", [(0, 0), (32, 1)])
+def test_linear_dgrad_sln_bwd(M, K, bcast, acc):
+    u = _u()
+    g = torch.Generator().manual_seed(M * 3 + K + bcast)
+    dY = u.rbf(torch.randn(M, K, generator=g))
+    W = u.rbf(torch.randn(K, E, generator=g) / math.sqrt(K))
+    hx = u.rbf(torch.randn(bcast if bcast else M, E, generator=g) * 1.5 + 0.3)
+    x = hx.repeat(M // bcast, 1) if bcast else hx
+    gres = u.rbf(torch.randn(M, E, generator=g))
+    wmod = u.rbf(torch.randn(M, E, generator=g))
+    lw, lb = 1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    gs, bs = 0.7, -0.3
+    dw0 = torch.randn(M, E, generator=g)
+    drop, seed, site = 0.2, 9, 100
+    mu = x.mean(1, keepdim=True)
+    rs = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xh = (x - mu) * rs
+    dxn = u.rbf(dY @ W)
+    l = xh * lw + lb
+    dw_ref = dxn * (gs * l + bs) + (dw0 if acc else 0.0)
+    dgs_ref, dbs_ref = float((dxn * wmod * l).sum()), float((dxn * wmod).sum())
+    de = dxn * wmod * gs
+    gg = de * lw
+    dx = u.rbf(gres + rs * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)))
+    dxm = u.rbf(dx * _mask(u, M, drop, seed, site))
+    terms = [de * xh, de, dxm]
+    WpT = _pack(u, W, K, True)
+    L = u._lib.lib()
+    nparts = L.vg_row_parts(M)
+    PW = 3 * E + 64
+    d_dY, d_h, d_gres, d_wm, d_lw, d_lb = u.dev(dY, u.BF), u.dev(hx, u.BF), u.dev(gres, u.BF), u.dev(wmod, u.BF), u.dev(lw), u.dev(lb)
+    d_sc = u.dev(torch.tensor([gs, bs]))
+    d_mu, d_rs = u.dev(mu.flatten()), u.dev(rs.flatten())
+    out = torch.empty(M, E, dtype=u.BF, device="cuda"); outm = torch.empty_like(out)
+    dwa = u.dev(dw0.clone())
+    part = torch.full((nparts + 1, PW), 7.0, device="cuda")
+    u.call("vg_linear_dgrad_sln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_h), bcast, u.ptr(d_wm), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_lw), u.ptr(d_lb),
+           u.ptr(d_sc), C.c_void_p(d_sc.data_ptr() + 4), u.ptr(d_gres), u.ptr(out), u.ptr(outm), u.ptr(dwa), acc, u.ptr(part), M, K, drop, seed, site, None, u.stream())
+    u.sync()
+    u.assert_close(out, dx, BF_TOL * 1.5, "dh")
+    u.assert_close(outm, dxm, BF_TOL * 1.5, "dhm")
+    u.assert_close(dwa, dw_ref, BF_TOL, "dw_acc")  # fp32 products of a bf16 GEMM result that may differ from the reference's by one ulp
+    assert bool((part[nparts:] == 7.0).all())
+    got = part[:nparts].sum(0).cpu()
+    for i, name in enumerate(("d lw", "d lb", "colsum")):
+        ref = terms[i].sum(0)
+        tol = 2.0 ** -8 * math.sqrt(M) * 1.5 * float(terms[i].abs().max()) + 1e-4 * float(ref.abs().max())
+        assert float((got[i * E:(i + 1) * E] - ref).abs().max()) <= tol, name
+    for val, ref, t in ((float(got[3 * E]), dgs_ref, dxn * wmod * l), (float(got[3 * E + 1]), dbs_ref, dxn * wmod)):
+        assert abs(val - ref) <= 2.0 ** -7 * float(t.norm()) + 1e-4 * abs(ref), (val, ref)

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "vg_row_parts": (c_int, [c_int]),
     "vg_linear_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_dgrad_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_sln_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_dgrad_sln_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
     "vg_colsum_bf16_parts": (c_int, [c_int]),
     "vg_colsum_bf16": (c_int, [P, c_ll, c_int, c_int, P, P, c_int, P]),

@@ -110,6 +110,37 @@ extern "C" int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
+extern "C" int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
+                                 void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
+                                 const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,
+                                 int site, const unsigned* step_dev, void* stream) {
+  if (!A || !Wp || !Y || !Yn || !mean || !rstd || !wmod || !lw || !lb || !gs || !bs || drop_p < 0.f || drop_p >= 1.f) return -1;
+  if (res && resf) return -1;
+  VgRowArgs ra = {};
+  ra.A = (const bf16*)A; ra.lda = K; ra.Wp = (const bf16*)Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = (const bf16*)res;
+  ra.resf = resf; ra.res_period = res_period;
+  ra.Y = (bf16*)Y; ra.Yn = (bf16*)Yn; ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = lw; ra.beta = lb; ra.eps = eps;
+  ra.wmod = (const bf16*)wmod; ra.gs = gs; ra.bs = bs;
+  row_drop(ra, drop_p, seed, site, step_dev);
+  const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
+extern "C" int vg_linear_dgrad_sln_bwd(const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
+                                       const float* mean, const float* rstd, const float* lw, const float* lb, const float* gs,
+                                       const float* bs, const void* gres, void* dh, void* dhm, float* dw_acc, int dw_accumulate,
+                                       float* part, int M, int K, float drop_p, unsigned long long seed, int site,
+                                       const unsigned* step_dev, void* stream) {
+  if (!dY || !WpT || !h || !wmod || !mean || !rstd || !lw || !lb || !gs || !bs || !dh || !dw_acc || !part || drop_p < 0.f || drop_p >= 1.f)
+    return -1;
+  VgRowArgs ra = {};
+  ra.A = (const bf16*)dY; ra.lda = K; ra.Wp = (const bf16*)WpT; ra.M = M; ra.K = K; ra.x = (const bf16*)h; ra.x_period = h_bcast_rows;
+  ra.mean = mean; ra.rstd = rstd; ra.gamma = lw; ra.lbias = lb; ra.gs = gs; ra.bs = bs; ra.wmod = (const bf16*)wmod;
+  ra.gres = (const bf16*)gres; ra.dx = (bf16*)dh; ra.dxm = (bf16*)dhm; ra.dw_acc = dw_acc; ra.dw_accumulate = dw_accumulate; ra.part = part;
+  if (dhm) row_drop(ra, drop_p, seed, site, step_dev);
+  if (dhm && !ra.drop_thresh) { ra.drop_thresh = 0; ra.drop_scale = 1.f; }
+  const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
 extern "C" int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
                                       const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
                                       float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream) {

@@ -578,7 +578,11 @@ struct GenWs {
   bf16 *g[3], *gm[2], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
   bf16 *y2, *dy2;  // patch-grid variant only: token rows [R, CW] before the un-patchify / after the patchify of d_img
   float *dw_acc, *part, *part_cs, *emb_sum, *slab;
+  bf16* wpack;  // E = 384: stage images of Wo | Wm | Wqkv^T | Wm^T per block, then s1_w^T, for the full-row GEMMs (gemm_row.hip)
 };
+// generator rows R = B*T: the full-row kernels (SLN in the epilogue) take the Linears whose output is the embedding when E = 384
+static inline int gen_row_nwg(const VgGenDims& d, int R) { return (d.E == VG_ROW_N && d.O % 64 == 0 && d.O >= 128) ? vg_row_nwg(R) : 0; }
+static inline long long gen_pack_block(const VgGenDims& d) { return 6LL * d.E * d.E; }  // E*E + E*E + 3E*E + E*E
 static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   const long long E = d.E, T = d.T, R = (long long)B * T, L = d.L;
   VgGenLayout lay; vg_gen_layout(&d, &lay);
@@ -616,6 +620,7 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   long long slab = GEN_SPLIT_CAP * lay.layer_weights;
   if (GEN_SPLIT_CAP * (long long)d.O * E > slab) slab = GEN_SPLIT_CAP * (long long)d.O * E;
   w.slab = c.take<float>(slab);
+  w.wpack = c.take<bf16>(gen_row_nwg(d, (int)R) ? L * gen_pack_block(d) + (long long)d.O * E : 0);
   return c.off;
 }
 extern "C" long long vg_gen_ws_bytes(const VgGenDims* d, int B) {
@@ -656,6 +661,33 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   VG_TRY(vg_cast_f32_bf16_launch(z, w.zb, (long long)B * d.Z, st));
   VG_TRY(lin_fwd(w.zb, d.Z, Pb + lay.map_w, P + lay.map_b, w.wmod, B, T * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
 
+  // full-row path: every Linear whose output is the embedding carries the SLN behind it in its epilogue (gemm_row.hip)
+  const int rown = gen_row_nwg(d, R);
+  const long long pb = gen_pack_block(d), po_wo = 0, po_wm = (long long)E * E, po_wqkvT = 2LL * E * E, po_wmT = 5LL * E * E;
+  if (rown) {
+    VgPackJobs pj;
+    pj.src = Pb + lay.layer0; pj.dst = w.wpack; pj.src_stride = lay.layer_stride; pj.dst_stride = pb; pj.nblocks = d.L; pj.n = 4;
+    pj.d[0] = {lay.wo, po_wo, E, E, 0};           // output_linear forward
+    pj.d[1] = {lay.wm, po_wm, E, E, 0};           // block MLP forward
+    pj.d[2] = {lay.wqkv, po_wqkvT, 3 * E, E, 1};  // q|k|v input gradient
+    pj.d[3] = {lay.wm, po_wmT, E, E, 1};          // block MLP input gradient
+    VG_TRY(vg_pack_rows_launch(pj, st));
+    VgPackJobs ph;                                // first SIREN layer's input gradient: s1_w [O, E] read transposed
+    ph.src = Pb + lay.s1_w; ph.dst = w.wpack + (long long)d.L * pb; ph.src_stride = 0; ph.dst_stride = 0; ph.nblocks = 1; ph.n = 1;
+    ph.d[0] = {0, 0, d.O, E, 1};
+    VG_TRY(vg_pack_rows_launch(ph, st));
+  }
+  // y = (res | emb table) + drop(A W^T + b);  yn = SLN(y, w)
+  auto row_fwd = [&](const bf16* A, const bf16* Wp, const float* bias, const bf16* res, const float* resf, bf16* Y, bf16* Yn, float* mean,
+                     float* rstd, const float* lw, const float* lb, const float* sc, int site) -> int {
+    VgRowArgs ra = {};
+    ra.A = A; ra.lda = E; ra.Wp = Wp; ra.M = R; ra.K = E; ra.bias = bias; ra.res = res; ra.resf = resf; ra.res_period = T; ra.Y = Y; ra.Yn = Yn;
+    ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = lw; ra.beta = lb; ra.eps = 1e-5f; ra.wmod = w.wmod; ra.gs = sc; ra.bs = sc + 1;
+    if (dr.thr) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
+    const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, st);
+    return r > 0 ? 0 : (r < 0 ? -r : -3);
+  };
+
   for (int l = 0; l < d.L; ++l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* h = (l == 0) ? Pb + lay.emb : w.hout + (size_t)(l - 1) * RE;
@@ -665,25 +697,40 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
     bf16* cat = w.cat + (size_t)l * RE;
     bf16* htmp = w.htmp + (size_t)l * RE;
     bf16* s2 = w.s2 + (size_t)l * RE;
-    VG_TRY(vg_sln_fwd_launch(h, hb, w.wmod, P + lo + lay.sln1_w, P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1,
-                             s1, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, R, E, 1e-5f, st));
+    const bf16* wp = w.wpack + (size_t)l * pb;
+    if (!rown || l == 0)  // block 0 normalises the broadcast embedding; later blocks got s1 from the MLP epilogue of the block below
+      VG_TRY(vg_sln_fwd_launch(h, hb, w.wmod, P + lo + lay.sln1_w, P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1,
+                               s1, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, R, E, 1e-5f, st));
     VG_TRY(lin_fwd(s1, E, Pb + lo + lay.wqkv, nullptr, qkv, R, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
     VG_TRY(vg_attn_fwd_launch(qkv, cat, w.lse + (size_t)l * B * d.H * T, B, d.H, T, HE, scale, 0, st));
-    {  // htmp = output_linear(cat) + h   (transformer.py:86); block 0 adds the broadcast embedding
-      VgGemmProb p = mk(cat, E, Pb + lo + lay.wo, E, R, E, E);
-      p.C = htmp; p.ldc = E; p.bias = P + lo + lay.bo;
-      if (l == 0) { p.resf = P + lay.emb; p.res_period = T; } else { p.res = h; p.ldr = E; }
-      set_drop(p, dr, 100 + 2 * l, 0);  // attention_dropout(msha(...)) + h, transformer.py:86
-      VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
+    if (rown) {  // htmp = output_linear(cat) + h (block 0: + the broadcast embedding) and SLN2(htmp) in one kernel
+      VG_TRY(row_fwd(cat, wp + po_wo, P + lo + lay.bo, l == 0 ? nullptr : h, l == 0 ? P + lay.emb : nullptr, htmp, s2,
+                     w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w, P + lo + lay.sln2_b, P + lo + lay.sln2_s, 100 + 2 * l));
+      // hout = drop(mlp(s2)) + htmp and the NEXT SLN of it: the block above's SLN1, or the final SLN in front of the SIREN
+      const bool nx = l + 1 < d.L;
+      const long long ln = lo + lay.layer_stride;
+      VG_TRY(row_fwd(s2, wp + po_wm, P + lo + lay.bm, htmp, nullptr, w.hout + (size_t)l * RE, nx ? w.s1 + (size_t)(l + 1) * RE : w.sf,
+                     nx ? w.mean1 + (size_t)(l + 1) * R : w.meanf, nx ? w.rstd1 + (size_t)(l + 1) * R : w.rstdf,
+                     nx ? P + ln + lay.sln1_w : P + lay.slnf_w, nx ? P + ln + lay.sln1_b : P + lay.slnf_b, nx ? P + ln + lay.sln1_s : P + lay.slnf_s,
+                     101 + 2 * l));
+    } else {
+      {  // htmp = output_linear(cat) + h   (transformer.py:86); block 0 adds the broadcast embedding
+        VgGemmProb p = mk(cat, E, Pb + lo + lay.wo, E, R, E, E);
+        p.C = htmp; p.ldc = E; p.bias = P + lo + lay.bo;
+        if (l == 0) { p.resf = P + lay.emb; p.res_period = T; } else { p.res = h; p.ldr = E; }
+        set_drop(p, dr, 100 + 2 * l, 0);  // attention_dropout(msha(...)) + h, transformer.py:86
+        VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
+      }
+      VG_TRY(vg_sln_fwd_launch(htmp, 0, w.wmod, P + lo + lay.sln2_w, P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1,
+                               s2, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, R, E, 1e-5f, st));
+      VG_TRY(lin_fwd(s2, E, Pb + lo + lay.wm, P + lo + lay.bm, w.hout + (size_t)l * RE, R, E, VG_ACT_NONE, 0.f, htmp, nullptr, nullptr, st,
+                     &dr, 101 + 2 * l));  // Sequential(Linear, Dropout) + htmp, muilti_layer_perceptron.py:26-28
     }
-    VG_TRY(vg_sln_fwd_launch(htmp, 0, w.wmod, P + lo + lay.sln2_w, P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1,
-                             s2, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, R, E, 1e-5f, st));
-    VG_TRY(lin_fwd(s2, E, Pb + lo + lay.wm, P + lo + lay.bm, w.hout + (size_t)l * RE, R, E, VG_ACT_NONE, 0.f, htmp, nullptr, nullptr, st,
-                   &dr, 101 + 2 * l));  // Sequential(Linear, Dropout) + htmp, muilti_layer_perceptron.py:26-28
   }
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
-  VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
-                           R, E, 1e-5f, st));
+  if (!rown)
+    VG_TRY(vg_sln_fwd_launch(hL, 0, w.wmod, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1, w.sf, w.meanf, w.rstdf,
+                             R, E, 1e-5f, st));
   if (net->pos_table) VG_TRY(vg_add_table_launch(w.sf, net->pos_table, R, E, T, st));  // constant: the backward is unchanged
   VG_TRY(lin_fwd(w.sf, E, Pb + lay.s1_w, P + lay.s1_b, w.y1, R, d.O, VG_ACT_SIN, d.omega0, nullptr, nullptr, w.zf1, st));
   bf16* rows = d.patch > 0 ? w.y2 : (bf16*)img;
@@ -708,14 +755,27 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
   const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
   const size_t RE = (size_t)R * E;
   const float scale = 1.0f / sqrtf((float)E);
-  const int parts = vg_ln_bwd_nparts(R);
-  const size_t part_sz = (size_t)parts * PW;
+  const int rown = gen_row_nwg(d, R);  // full-row path: the forward packed the weights into this workspace
+  const int parts = rown ? rown : vg_ln_bwd_nparts(R);
+  const long long pb = gen_pack_block(d), po_wqkvT = 2LL * E * E, po_wmT = 5LL * E * E;
+  const size_t part_sz = (size_t)vg_ln_bwd_nparts(R) * PW;  // slot stride in the workspace (sized for the standalone kernels)
   VgFoldJobs folds; folds.n = 0;
   const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
   const bool drop = dr.thr != 0;
   bf16* const gm2buf = w.gm[0];  // g masked for the MLP-branch dropout it meets next
   bf16* const gm1buf = w.gm[1];  // gmid masked for the attention-branch dropout
 
+  // dh = gres + SLN'(A W) in one kernel
+  auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* hx, int hbc, const float* mean, const float* rstd, const float* lw,
+                     const float* lb, const float* sc, const bf16* gres, bf16* dh, bf16* dhm, int accumulate, float* part, int site) -> int {
+    VgRowArgs ra = {};
+    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = R; ra.K = K; ra.x = hx; ra.x_period = hbc; ra.mean = mean; ra.rstd = rstd; ra.gamma = lw; ra.lbias = lb;
+    ra.gs = sc; ra.bs = sc + 1; ra.wmod = w.wmod; ra.gres = gres; ra.dx = dh; ra.dxm = dhm; ra.dw_acc = w.dw_acc; ra.dw_accumulate = accumulate;
+    ra.part = part;
+    if (dhm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
+    const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, st);
+    return r > 0 ? 0 : (r < 0 ? -r : -3);
+  };
   bf16 *g = w.g[0], *gmid = w.g[1], *gin = w.g[2];
   if (stage_begin == 0) {
   // SIREN output layers (siren.py:44-45): y = sin(w0 z)  ->  dz = dy * w0 cos(w0 z)
@@ -740,10 +800,15 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.O * E, p.splits, G + lay.s1_w, (long long)d.O * E, 1, st));
   }
-  VG_TRY(lin_dgrad(w.dz1, Pb + lay.s1_w, w.ds, R, d.O, E, 0, nullptr, nullptr, 0.f, st));
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
-  VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
-                           nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
+  if (rown) {  // first SIREN layer's input gradient + the final SLN's backward
+    VG_TRY(row_bwd(w.dz1, d.O, w.wpack + (long long)d.L * pb, hL, 0, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, nullptr, g,
+                   drop ? gm2buf : nullptr, 0, w.part + (size_t)(2 * d.L) * part_sz, 101 + 2 * (d.L - 1)));
+  } else {
+    VG_TRY(lin_dgrad(w.dz1, Pb + lay.s1_w, w.ds, R, d.O, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
+                             nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
+  }
   {
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2));
@@ -763,16 +828,22 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     const bf16* s2 = w.s2 + (size_t)l * RE;
     // hout = drop(mlp(s2)) + htmp  (transformer.py:87; MLP is a single Linear, muilti_layer_perceptron.py:37-42)
     const bf16* gb2 = drop ? gm2buf : g;
-    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_sln_bwd_launch(w.ds, htmp, 0, w.wmod, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w,
-                             P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part + (size_t)(2 * l) * part_sz, R, E,
-                             drop ? gm1buf : nullptr, dr.thr, site_key(dr, 100 + 2 * l), dr.scale, dr.step, st));
+    const bf16* wp = w.wpack + (size_t)l * pb;
+    if (rown) {  // block MLP input gradient + SLN2 backward + the residual-stream gradient
+      VG_TRY(row_bwd(gb2, E, wp + po_wmT, htmp, 0, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w, P + lo + lay.sln2_b,
+                     P + lo + lay.sln2_s, g, gmid, drop ? gm1buf : nullptr, 1, w.part + (size_t)(2 * l) * part_sz, 100 + 2 * l));
+    } else {
+      VG_TRY(lin_dgrad(gb2, Pb + lo + lay.wm, w.ds, R, E, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_sln_bwd_launch(w.ds, htmp, 0, w.wmod, w.mean2 + (size_t)l * R, w.rstd2 + (size_t)l * R, P + lo + lay.sln2_w,
+                               P + lo + lay.sln2_b, P + lo + lay.sln2_s, P + lo + lay.sln2_s + 1, g, gmid, w.dw_acc, 1, w.part + (size_t)(2 * l) * part_sz, R, E,
+                               drop ? gm1buf : nullptr, dr.thr, site_key(dr, 100 + 2 * l), dr.scale, dr.step, st));
+    }
     const bf16* gb1 = drop ? gm1buf : gmid;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
                  G + lo + lay.sln2_s, 2));
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, 0, st));
-    VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    if (!rown) VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     {
       const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);
       int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
@@ -785,9 +856,14 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
       VG_TRY(vg_gemm_launch(pr, 3, VG_TN, st));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
     }
-    VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
-                             P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part + (size_t)(2 * l + 1) * part_sz, R, E,
-                             (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
+    if (rown) {  // q|k|v input gradient + SLN1 backward + the residual-stream gradient
+      VG_TRY(row_bwd(w.dqkv, 3 * E, wp + po_wqkvT, h, hb, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w, P + lo + lay.sln1_b,
+                     P + lo + lay.sln1_s, gmid, gin, (drop && l > 0) ? gm2buf : nullptr, 1, w.part + (size_t)(2 * l + 1) * part_sz, 101 + 2 * (l - 1)));
+    } else {
+      VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
+                               P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part + (size_t)(2 * l + 1) * part_sz, R, E,
+                               (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
+    }
     float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2));
     bf16* t = g; g = gin; gin = t;

@@ -45,12 +45,12 @@ constexpr int RW_MAXMT = RW_MAXMT_;  // m-tiles per tile (tuning builds: make va
 constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
 constexpr int RW_NSLOT = 4;
 constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
-constexpr int RW_GAM = RW_E * 4;                       // behind the ring: gamma in fp32 (the LNBWD epilogue has no registers for it)
+constexpr int RW_GAM = 2 * RW_E * 4;                   // behind the ring: gamma (and the SLN's bias) in fp32 - the LNBWD epilogue has no registers for them
 constexpr int RW_TS = 784;                             // row stride of the bf16 epilogue tile (LNBWD): 768 + 16 (ds_write_b64 2-way at worst)
 constexpr int RW_TSF = 1552;                           // row stride of the fp32 epilogue tile (LNFWD, 80 rows at a time): 1536 + 16
 static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
 static_assert(80 * RW_TSF <= RW_RING, "fp32 half tile must fit the ring");
-static_assert(3 * 8 * RW_E * 4 <= RW_RING, "column-sum fold must fit the ring");
+static_assert((3 * 8 * RW_E + 16) * 4 <= RW_RING, "column-sum fold must fit the ring");
 
 // row-form chunk swizzle of gemm.hip: 16-B chunk c of row r lives at position c ^ {0,2,3,1}[(r>>2)&3]
 __device__ __host__ __forceinline__ int rw_row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
@@ -85,7 +85,7 @@ __device__ __forceinline__ float rw_row16_sum(float v) {
 #else
 #define RW_DBG(bit) 0
 #endif
-template <int EPI>
+template <int EPI, bool SLN>
 __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING + RW_GAM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -97,8 +97,11 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
   const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
 
-  if (EPI == VG_ROW_LNBWD && tid < RW_E / 4)  // visible to everyone behind the first tile's barriers
+  if (EPI == VG_ROW_LNBWD && tid < RW_E / 4) {  // visible to everyone behind the first tile's barriers
     *(f32x4*)(smem + RW_RING + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
+    if (SLN) *(f32x4*)(smem + RW_RING + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.lbias + 4 * tid);
+  }
+  float cum_s = 0.f;               // LNBWD + SLN: threads 0 / 1 carry d gs / d bs
   float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
 
   auto tile = [&](auto mt_c, const int m0) {
@@ -219,6 +222,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     VgRowArgs e = a;
     asm volatile("" : "+s"(e.bias), "+s"(e.res), "+s"(e.Y), "+s"(e.Yn), "+s"(e.mean_out), "+s"(e.rstd_out), "+s"(e.beta), "+s"(e.gamma));
     asm volatile("" : "+s"(e.x), "+s"(e.mean), "+s"(e.rstd), "+s"(e.gres), "+s"(e.dx), "+s"(e.dxm));
+    asm volatile("" : "+s"(e.wmod), "+s"(e.gs), "+s"(e.bs), "+s"(e.dw_acc), "+s"(e.resf));
+    const float g_s = SLN ? e.gs[0] : 1.f, b_s = SLN ? e.bs[0] : 0.f;
     if (EPI == VG_ROW_LNFWD) {
       // LNFWD keeps the sum in fp32 until the residual is added (ONE rounding, as the unfused epilogue had): fp32 tile rows of
       // 1552 B, 5 m-tiles (80 rows) at a time
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         const int rows = 16 * hm, passes = (rows + 31) / 32;
         // residual rows of pass 0 (phase-2 layout): in flight across the dump
         bf16x8 rn[3];  // residual rows of the NEXT pass
+        bf16x8 wn[SLN ? 3 : 1];  // SLN: modulation rows of the next pass
         auto ld_res = [&](bf16x8 (&dst)[3], int ps) {
           const int rl = 32 * ps + 4 * wid + rg;
           const size_t row = (size_t)(m0 + 16 * mt0 + (rl < rows ? rl : 0));
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           for (int i = 0; i < 3; ++i) {
             dst[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (e.res && !RW_DBG(32)) dst[i] = *(const bf16x8*)(e.res + row * RW_E + 8 * (sub + 16 * i));
+            if (SLN) wn[SLN ? i : 0] = *(const bf16x8*)(e.wmod + row * RW_E + 8 * (sub + 16 * i));
           }
         };
         ld_res(rn, 0);
@@ -283,6 +290,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           {
             const int rem = rows - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
             bf16x8 rc[3] = {rn[0], rn[1], rn[2]};
+            bf16x8 wc[SLN ? 3 : 1];
+            if (SLN) { wc[0] = wn[0]; wc[SLN ? 1 : 0] = wn[SLN ? 1 : 0]; wc[SLN ? 2 : 0] = wn[SLN ? 2 : 0]; }
             if (ps + 1 < passes) ld_res(rn, ps + 1);
             if (rem >= 32 || wid < 4) {
               const int rl = 32 * ps + 4 * wid + rg;
@@ -294,10 +303,17 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
                 const f32x4 t0 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i));
                 const f32x4 t1 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i) + 16);
                 bf16x8 o;
+                if (e.resf) {  // residual from an fp32 table, broadcast over the batch (block 0 of the generator: the learned embedding)
+                  const float* rf = e.resf + (size_t)((int)(row % (size_t)a.res_period)) * RW_E + 8 * (sub + 16 * i);
+                  const f32x4 r0 = *(const f32x4*)rf, r1 = *(const f32x4*)(rf + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  o[j] = vg_f2bf(t0[j] + vg_bf2f(rc[i][j]));
-                  o[j + 4] = vg_f2bf(t1[j] + vg_bf2f(rc[i][j + 4]));
+                  for (int j = 0; j < 4; ++j) { o[j] = vg_f2bf(t0[j] + r0[j]); o[j + 4] = vg_f2bf(t1[j] + r1[j]); }
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    o[j] = vg_f2bf(t0[j] + vg_bf2f(rc[i][j]));
+                    o[j + 4] = vg_f2bf(t1[j] + vg_bf2f(rc[i][j + 4]));
+                  }
                 }
                 if (!RW_DBG(8)) *(bf16x8*)(e.Y + row * RW_E + 8 * (sub + 16 * i)) = o;
 #pragma unroll
@@ -316,7 +332,11 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
                 for (int i = 0; i < 3; ++i) {
                   bf16x8 o;
 #pragma unroll
-                  for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(fmaf((v[i][j] - mu) * rs, gam[i][j], bet[i][j]));
+                  for (int j = 0; j < 8; ++j) {
+                    float r = fmaf((v[i][j] - mu) * rs, gam[i][j], bet[i][j]);
+                    if (SLN) r = vg_bf2f(wc[SLN ? i : 0][j]) * fmaf(g_s, r, b_s);
+                    o[j] = vg_f2bf(r);
+                  }
                   if (!RW_DBG(8)) *(bf16x8*)(e.Yn + row * RW_E + 8 * (sub + 16 * i)) = o;
                 }
               }
@@ -325,20 +345,27 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         }
       }
     } else {
-      constexpr int ROWS = 16 * MT, PASSES = (ROWS + 31) / 32;
+      // LPR lanes per row: 16 (16-byte chunks, 4 rows per wave and pass) for the plain LayerNorm; 32 (8-byte chunks, 2 rows) for the
+      // self-modulated one, whose extra operands (w, d w, the LayerNorm's bias) would not leave room for 72 column accumulators
+      constexpr int LPR = SLN ? 32 : 16, CH = 128 / LPR, RPW = 64 / LPR, RPP = 8 * RPW;
+      constexpr int ROWS = 16 * MT, PASSES = (ROWS + RPP - 1) / RPP;
+      typedef typename std::conditional<CH == 8, bf16x8, bf16x4>::type chunk_t;
+      const int subl = ln % LPR, rgl = ln / LPR;
       const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
       const float dscale = a.drop_scale;
-      // operands of pass 0 in flight across the dump
-      bf16x8 xn[3];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
+      auto zero_chunk = [] { chunk_t z; for (int j = 0; j < CH; ++j) z[j] = (bf16)0.f; return z; };
+      auto row_sum = [&](float v) { v = rw_row16_sum(v); if (LPR == 32) v += __shfl_xor(v, 16, 64); return v; };
+      chunk_t xn[3];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
       float mun, rsn;
       auto ld_ops = [&](int ps) {
-        const int rl = 32 * ps + 4 * wid + rg;
+        const int rl = RPP * ps + RPW * wid + rgl;
         const size_t row = (size_t)(m0 + (rl < ROWS ? rl : 0));
+        const size_t xrow = a.x_period > 0 ? (size_t)((int)(row % (size_t)a.x_period)) : row;  // x broadcast over the batch (generator block 0)
         mun = e.mean[row]; rsn = e.rstd[row];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          xn[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-          if (!RW_DBG(16)) xn[i] = *(const bf16x8*)(e.x + row * RW_E + 8 * (sub + 16 * i));
+          xn[i] = zero_chunk();
+          if (!RW_DBG(16)) xn[i] = *(const chunk_t*)(e.x + xrow * RW_E + CH * (subl + LPR * i));
         }
       };
       ld_ops(0);
@@ -353,85 +380,124 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           *(bf16x4*)(smem + (16 * mt + li) * RW_TS + (48 * wid + 16 * nt + 4 * g) * 2) = o;
         }
       __syncthreads();
-      float ag[3][8], ab[3][8], ac[3][8];
+      float ag[3][CH], ab[3][CH], ac[3][CH];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
+        for (int j = 0; j < CH; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
       const unsigned char* gam_lds = smem + RW_RING;
+      float s_gs = 0.f, s_bs = 0.f;  // SLN: d gs = sum dy w (xhat gamma + lbias), d bs = sum dy w
+      auto ld_f32 = [&](const unsigned char* base, int i, float (&dst)[CH]) {
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          const f32x4 t4 = *(const f32x4*)(base + 4 * (CH * (subl + LPR * i) + 4 * q));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dst[4 * q + j] = t4[j];
+        }
+      };
 #pragma unroll 1
       for (int ps = 0; ps < PASSES; ++ps) {
-        const int rem = ROWS - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
-        bf16x8 xc[3] = {xn[0], xn[1], xn[2]};
+        const int rem = ROWS - RPP * ps;  // LPR 16: 16 or >= 32 - with 16 only waves 0..3 have rows; LPR 32: always a whole pass
+        chunk_t xc[3] = {xn[0], xn[1], xn[2]};
         const float mu = mun, rs = rsn;
         if (ps + 1 < PASSES) ld_ops(ps + 1);
-        if (rem >= 32 || wid < 4) {
-          const int rl = 32 * ps + 4 * wid + rg;
+        if (rem >= RPP || wid < 4) {
+          const int rl = RPP * ps + RPW * wid + rgl;
           const size_t row = (size_t)(m0 + rl);
-          bf16x8 gr[3];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
+          chunk_t gr[3];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
+          chunk_t wm[SLN ? 3 : 1];
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            gr[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-            if (e.gres && !RW_DBG(16)) gr[i] = *(const bf16x8*)(e.gres + row * RW_E + 8 * (sub + 16 * i));
+            if (SLN) wm[SLN ? i : 0] = *(const chunk_t*)(e.wmod + row * RW_E + CH * (subl + LPR * i));
+            gr[i] = zero_chunk();
+            if (e.gres && !RW_DBG(16)) gr[i] = *(const chunk_t*)(e.gres + row * RW_E + CH * (subl + LPR * i));
           }
-          float xh[3][8], gg[3][8];
+          float xh[3][CH], gg[3][CH];
           float c1 = 0.f, c2 = 0.f;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            const bf16x8 t = *(const bf16x8*)(smem + rl * RW_TS + 16 * (sub + 16 * i));
-            const f32x4 gm0 = *(const f32x4*)(gam_lds + 32 * (sub + 16 * i)), gm1 = *(const f32x4*)(gam_lds + 32 * (sub + 16 * i) + 16);
+            const chunk_t t = *(const chunk_t*)(smem + rl * RW_TS + 2 * CH * (subl + LPR * i));
+            float gm[CH], lb[SLN ? CH : 1], dwv[SLN ? CH : 1];
+            ld_f32(gam_lds, i, gm);
+            if (SLN) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+              for (int q = 0; q < CH / 4; ++q) {
+                const f32x4 t4 = *(const f32x4*)(gam_lds + RW_E * 4 + 4 * (CH * (subl + LPR * i) + 4 * q));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lb[SLN ? 4 * q + j : 0] = t4[j];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
               const float h = (vg_bf2f(xc[i][j]) - mu) * rs;
-              const float d = vg_bf2f(t[j]);
+              float d = vg_bf2f(t[j]);
+              if (SLN) {  // norm.hip's SLN backward: the modulation's own gradients first, then dy_eff = dy w gs
+                const float wv = vg_bf2f(wm[SLN ? i : 0][j]);
+                const float l = fmaf(h, gm[j], lb[SLN ? j : 0]);
+                dwv[SLN ? j : 0] = d * fmaf(g_s, l, b_s);
+                const float dwm = d * wv;
+                s_gs = fmaf(dwm, l, s_gs);
+                s_bs += dwm;
+                d = dwm * g_s;
+              }
               xh[i][j] = h;
               ag[i][j] = fmaf(d, h, ag[i][j]);
               ab[i][j] += d;
-              const float gv = d * (j < 4 ? gm0[j] : gm1[j - 4]);
+              const float gv = d * gm[j];
               gg[i][j] = gv;
               c1 += gv;
               c2 = fmaf(gv, h, c2);
             }
+            if (SLN) {  // d w: fp32, accumulated over the 2L + 1 uses of the modulation vector (CH = 4: one 16-byte access)
+              float* dwp = e.dw_acc + row * RW_E + CH * (subl + LPR * i);
+              f32x4 w0 = {dwv[0], dwv[SLN ? 1 : 0], dwv[SLN ? 2 : 0], dwv[SLN ? 3 : 0]};
+              if (a.dw_accumulate) w0 += *(const f32x4*)dwp;
+              *(f32x4*)dwp = w0;
+            }
           }
-          c1 = rw_row16_sum(c1) * (1.0f / RW_E);
-          c2 = rw_row16_sum(c2) * (1.0f / RW_E);
+          c1 = row_sum(c1) * (1.0f / RW_E);
+          c2 = row_sum(c2) * (1.0f / RW_E);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            const int c = 8 * (sub + 16 * i);
-            bf16x8 o;
+            const int c = CH * (subl + LPR * i);
+            chunk_t o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), vg_bf2f(gr[i][j])));
-            if (!RW_DBG(8)) *(bf16x8*)(e.dx + row * RW_E + c) = o;
+            for (int j = 0; j < CH; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), vg_bf2f(gr[i][j])));
+            if (!RW_DBG(8)) *(chunk_t*)(e.dx + row * RW_E + c) = o;
             if (e.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
               const unsigned i4 = ((unsigned)row * (unsigned)RW_E + (unsigned)c) >> 2;
 #pragma unroll
-              for (int q = 0; q < 2; ++q) {
+              for (int q = 0; q < CH / 4; ++q) {
                 const unsigned wd = vg_drop_word(dkey, i4 + q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[4 * q + j] = vg_f2bf(vg_bf2f(o[4 * q + j]) * vg_drop_factor(wd, j, dthr, dscale));
               }
-              if (!RW_DBG(8)) *(bf16x8*)(e.dxm + row * RW_E + c) = o;
+              if (!RW_DBG(8)) *(chunk_t*)(e.dxm + row * RW_E + c) = o;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ac[i][j] += vg_bf2f(o[j]);
+            for (int j = 0; j < CH; ++j) ac[i][j] += vg_bf2f(o[j]);
           }
         }
       }
-      // fold the column sums: the 4 row groups of a wave (shuffles), then the 8 waves (LDS, over the tile), fixed order
+      // fold the column sums: the row groups of a wave (shuffles), then the 8 waves (LDS, over the tile), fixed order
       __syncthreads();  // the tile has been read
-      float* red = (float*)smem;  // [3][8][384]
+      float* red = (float*)smem;  // [3][8][384] (+ 16 scalars)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CH; ++j) {
           float sa = ag[i][j], sb = ab[i][j], sc = ac[i][j];
-          sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64); sc += __shfl_xor(sc, 16, 64);
+          if (LPR == 16) { sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64); sc += __shfl_xor(sc, 16, 64); }
           sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64); sc += __shfl_xor(sc, 32, 64);
-          if (rg == 0) {
-            const int col = 8 * (sub + 16 * i) + j;
+          if (rgl == 0) {
+            const int col = CH * (subl + LPR * i) + j;
             red[(0 * 8 + wid) * RW_E + col] = sa; red[(1 * 8 + wid) * RW_E + col] = sb; red[(2 * 8 + wid) * RW_E + col] = sc;
           }
         }
+      if (SLN) {  // the two scalars: wave sums behind the column sums' region
+        const float a_ = vg_wave_sum(s_gs), b_ = vg_wave_sum(s_bs);
+        if (lane == 0) { red[3 * 8 * RW_E + 2 * wid] = a_; red[3 * 8 * RW_E + 2 * wid + 1] = b_; }
+      }
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -441,6 +507,10 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           const float* r0 = red + (which * 8) * RW_E + col;
           cum[k] += ((r0[0] + r0[RW_E]) + (r0[2 * RW_E] + r0[3 * RW_E])) + ((r0[4 * RW_E] + r0[5 * RW_E]) + (r0[6 * RW_E] + r0[7 * RW_E]));
         }
+      }
+      if (SLN && tid < 2) {
+        const float* r0 = red + 3 * 8 * RW_E + tid;
+        cum_s += ((r0[0] + r0[2]) + (r0[4] + r0[6])) + ((r0[8] + r0[10]) + (r0[12] + r0[14]));
       }
     }
   };
@@ -465,12 +535,13 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     n -= mt; m0 += 16 * mt; first = false;
   }
   if (EPI == VG_ROW_LNBWD) {
-    float* out = a.part + (size_t)blockIdx.x * (3 * RW_E);
+    float* out = a.part + (size_t)blockIdx.x * a.part_w;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = tid + 512 * k;
       if (c < 3 * RW_E) out[c] = cum[k];
     }
+    if (SLN && tid < 2) out[3 * RW_E + tid] = cum_s;
   }
 }
 
@@ -529,12 +600,18 @@ int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
   a.dbg = getenv("VG_ROW_DBG") ? atoi(getenv("VG_ROW_DBG")) : 0;
   if (a.dbg & 1) a.lda = 0;  // every row of A is row 0: the A stream comes from L2
 #endif
+  const bool sln = a.wmod != nullptr;
+  if (sln && (!a.gs || !a.bs)) return -1;
   if (epi == VG_ROW_LNFWD) {
-    if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta))) return -1;
-    hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD>), dim3(nwg), dim3(512), 0, st, a);
+    if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta)) || (sln && !a.Yn)) return -1;
+    if (a.resf && (a.res || a.res_period < 1)) return -1;
+    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, true>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, false>), dim3(nwg), dim3(512), 0, st, a);
   } else if (epi == VG_ROW_LNBWD) {
-    if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || !a.part) return -1;
-    hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD>), dim3(nwg), dim3(512), 0, st, a);
+    if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || !a.part || (sln && (!a.lbias || !a.dw_acc))) return -1;
+    a.part_w = 3 * RW_E + (sln ? 64 : 0);
+    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, true>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, false>), dim3(nwg), dim3(512), 0, st, a);
   } else {
     return -4;
   }

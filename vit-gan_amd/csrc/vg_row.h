@@ -27,6 +27,16 @@ struct VgRowArgs {
   const bf16* gres;        // [M, 384] gradient arriving over the residual connection (nullable)
   bf16* dx; bf16* dxm;     // [M, 384]; dxm nullable
   float* part;             // [nwg][3*384]: per workgroup column sums  d gamma | d beta | colsum(dxm ? dxm : dx)
+  // ---- self-modulated LayerNorm (v1 generator, src/v1/spectral_layer_norm.py:19-20): wmod != nullptr -------------------------
+  //      forward:  yn = w * (gs * (LN(y) * gamma + beta) + bs);   backward: dy_eff = dy * w * gs feeds the LayerNorm backward,
+  //      dw_acc (+)= dy * (gs * (xhat * gamma + lbias) + bs), and the partial row gets d gs, d bs at [3*384], [3*384 + 1]
+  const bf16* wmod;        // [M, 384] modulation rows
+  const float* gs; const float* bs;  // device scalars
+  const float* lbias;      // LNBWD: [384] the LayerNorm's bias
+  float* dw_acc; int dw_accumulate;  // LNBWD: fp32 [M, 384]
+  const float* resf; int res_period; // LNFWD: residual from an fp32 table [res_period, 384] indexed by row % res_period (instead of res)
+  int x_period;            // LNBWD: x has x_period rows, broadcast over the batch (0: one row of x per row of A)
+  int part_w;              // LNBWD: row stride of part (filled by the launcher: 3*384, or 3*384 + 64 with wmod)
   // ---- both -------------------------------------------------------------------------------------------------------
   const float* gamma;      // [384]
   unsigned drop_thresh, drop_key; float drop_scale; const unsigned* drop_step;  // LNFWD: mask of drop(.); LNBWD: mask of dxm
