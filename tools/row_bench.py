@@ -34,7 +34,7 @@ def timeit(fn):
 
 
 tag = os.environ.get("VG_ROW_DBG", "0")
-for M in (33280, 16640):
+for M in [int(m) for m in os.environ.get("MS", "33280,16640").split(",")]:
     row = []
     for K in (384, 768, 1152, 2304):
         a = torch.randn(M, K, device="cuda").to(BF)

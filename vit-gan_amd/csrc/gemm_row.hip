@@ -586,7 +586,10 @@ int vg_pack_rows_launch(const VgPackJobs& jobs, hipStream_t st) {
 int vg_row_nwg(int M) {
   if (M < 16 || (M & 15)) return 0;
   const int units = M / 16;
-  const int want = (units + 3) / 4;  // at least ~4 units (64 rows) per workgroup while the chip is not full
+#ifndef RW_MINUNITS
+#define RW_MINUNITS 4
+#endif
+  const int want = (units + RW_MINUNITS - 1) / RW_MINUNITS;  // at least ~RW_MINUNITS units per workgroup while the chip is not full
   return want < 256 ? want : 256;
 }
 
