@@ -140,7 +140,8 @@ def step_roofline(torch, B, reps=30):
     part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
     lse = torch.zeros(2 * B * 4 * 65, device="cuda")
     dw = torch.zeros(1152, 384, device="cuda")
-    slab = torch.empty(4 * 1152 * 384, device="cuda")
+    WG_SPLITS = 28  # 9 tiles of 128 x 384 x 28 K slices = 252 workgroups, as the engine's grouped launch fills the chip (12 slices x 21 tiles)
+    slab = torch.empty(WG_SPLITS * 1152 * 384, device="cuda")
     S, H, HE = 65, 4, 96
 
     def chk(rc, what):
@@ -155,9 +156,9 @@ def step_roofline(torch, B, reps=30):
          lambda: chk(L.vg_linear_ln_fwd(p(x768), p(w2_p), p(bias), p(res), p(o384), p(o384b), p(mean), p(rstd), p(gam), p(bet), M, 768, 1e-5,
                                         0.1, 1, 2, None, st), "vg_linear_ln_fwd"),
          2.0 * M * 384 * 768, 2 * (M * 768 + 384 * 768 + 3 * M * 384) + 8 * M, "row fc2+res+ln fwd"),
-        ("vg_gemm_tn384_kernel<6>: QKV weight gradient (one of the four problems of a block's grouped launch)", [1152, 384, M],
-         lambda: chk(L.vg_linear_wgrad(p(x1152), p(x384), p(dw), p(slab), slab.numel(), M, 1152, 384, 4, 1, st), "vg_linear_wgrad"),
-         2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384) + 4 * 4 * 1152 * 384, "tn qkv wgrad"),
+        ("vg_gemm_tn384_kernel<6>: QKV weight gradient (one of the four problems of a block's grouped launch; + its slab fold)", [1152, 384, M],
+         lambda: chk(L.vg_linear_wgrad(p(x1152), p(x384), p(dw), p(slab), slab.numel(), M, 1152, 384, WG_SPLITS, 1, st), "vg_linear_wgrad"),
+         2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384) + 4 * WG_SPLITS * 1152 * 384, "tn qkv wgrad"),
         ("vg_attn_bwd_kernel<96,5>: fused attention backward, one workgroup per (image, head)", [2 * B, H, S, HE],
          lambda: chk(L.vg_attention_bwd(p(x1152), p(x384), p(res), p(lse), p(o1152), 2 * B, H, S, HE, 1.0 / HE ** 0.5, st), "vg_attention_bwd"),
          10.0 * 2 * B * H * S * S * HE, 2 * (M * 1152 * 2 + M * 384 * 2) + 4 * 2 * B * H * S, None),
@@ -216,7 +217,11 @@ def main():
                     help="c2 (default, the metric's configuration): 32x32 patch 4 E=384 4 heads, v1 row-token generator; "
                          "c4: 64x64 patch 8 E=512 8 heads; c5: 128x128 patch 16 E=768 12 heads (bf16 attention) - "
                          "both with the patch-grid generator (SURVEY 8f f1); extra measurements, not the headline")
-    ap.add_argument("--loss", default="ns", choices=["ns", "hinge"])
+    ap.add_argument("--loss", default="ns", choices=["ns", "hinge", "wasserstein"])
+    ap.add_argument("--gp", type=float, default=0.0,
+                    help="weight of the WGAN-GP gradient penalty in the discriminator step (src/v2/training.py:101-106; 10 with --loss wasserstein is "
+                         "the reference's unreached recipe): an extra measurement, not the headline - the penalty runs through torch autograd over "
+                         "the twice-differentiable operators and forces the eager (non-graph) step")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the step as a hipGraph (on > 1 GPU the capture includes the RCCL all-reduces); 0: eager; -1 (default): "
                          "on - the engine falls back to eager, loudly, when the process group cannot be captured (gloo)")
@@ -297,10 +302,10 @@ def main():
     else:
         G = SirenGenerator(image_size=IMG, embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
                            dropout=0.2 if args.dropout else 0.0).to(dev).train()
-    use_graph = True if args.graph < 0 else bool(args.graph)
+    use_graph = (True if args.graph < 0 else bool(args.graph)) and args.gp == 0.0
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                     concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
-                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1)
+                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
@@ -363,7 +368,7 @@ def main():
                                     "c5": "C5 shape: 3x128x128, patch 16 (65 tokens), E=768, 12 heads, 6 blocks ViT discriminator + patch-grid "
                                           "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW"}[args.workload],
                        "fp8_attention": fp8_attn,
-                       "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "dropout": {"D": eng.p_d, "G": eng.p_g},
+                       "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "gp_weight": args.gp, "dropout": {"D": eng.p_d, "G": eng.p_g},
                        "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": eng.graph_active,
                        "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1,
                        "fused_real_fake_pass": not args.no_fuse,

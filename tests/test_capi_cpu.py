@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.vg_attention_fwd(None, None, None, 1, 1, 1, 32, 1.0, None) == -1
     assert lib.vg_linear_fwd(None, None, None, None, None, None, None, 8, 8, 8, 0, 0.0, None) == -1
     # full-row Linear + LayerNorm entry points (csrc/gemm_row.hip): host-side shape queries and null checks
-    assert lib.vg_row_parts(33280) == 256 and lib.vg_row_parts(16640) == 256 and lib.vg_row_parts(2080) == 33 and lib.vg_row_parts(130) == 0
+    assert lib.vg_row_parts(33280) == 256 and lib.vg_row_parts(16640) == 256 and lib.vg_row_parts(2080) == 65 and lib.vg_row_parts(130) == 0
     assert lib.vg_row_pack_elems(384) == 384 * 384 and lib.vg_row_pack_elems(40) == -2
     assert lib.vg_row_pack_weight(None, 384, 384, 0, None, None) == -1
     assert lib.vg_linear_ln_fwd(None, None, None, None, None, None, None, None, None, None, 32, 384, 1e-5, 0.0, 0, 0, None, None) == -1

@@ -6,7 +6,7 @@ LayerNorm in front of them (modules.py:178-181).  Inputs are rounded to bf16 fir
 bf16 once (as the unfused kernels did at their HBM round trip), so the references do the same: tolerance 2^-7 of max|ref|
 for bf16 outputs (plus one ulp of the intermediate), 3e-5 for fp32 statistics, 1e-4 for the column sums.
 
-Row counts: M = 16 * units over min(256, ceil(units / 4)) workgroups - the sizes below give tiles of 1..9 m-tiles, several
+Row counts: M = 16 * units over min(256, ceil(units / 2)) workgroups - the sizes below give tiles of 1..9 m-tiles, several
 tiles per workgroup (M = 66 560: 16-17 units each) and the full C2 launches (M = 16 640 / 33 280: 4-5 and 8-9 units)."""
 import ctypes as C
 import math
@@ -184,7 +184,7 @@ def test_row_kernel_race_screen(M, K):
 @pytest.mark.parametrize("K", [384, 1152])
 def test_rows_do_not_depend_on_the_tile_they_land_in(K):
     """A row's result must be BIT-identical whatever the batch around it: the same 2 080 rows are run as a problem of their own
-    (tiles of 3-4 m-tiles), as the head of 16 640 rows (4-5 m-tiles) and of 33 280 rows (8-9 m-tiles).  The epilogue is
+    (tiles of 2 m-tiles), as the head of 16 640 rows (4-5 m-tiles) and of 33 280 rows (8-9 m-tiles).  The epilogue is
     instantiated per tile height; this is what catches a multiply-add contracted in one instantiation and not in another."""
     u = _u()
     g = torch.Generator().manual_seed(11)

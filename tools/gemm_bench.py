@@ -31,10 +31,10 @@ SHAPES = [
     ("row fc1 dgrad+ln bwd", 2.0 * M * 384 * 768, 2 * (M * 768 + 384 * 768 + 4 * M * 384) + 8 * M),
     ("wr out dgrad", 2.0 * M * 384 * 384, 2 * (M * 384 + 384 * 384 + M * 384)),
     ("row qkv dgrad+ln bwd", 2.0 * M * 384 * 1152, 2 * (M * 1152 + 384 * 1152 + 4 * M * 384) + 8 * M),
-    ("tn qkv wgrad", 2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384)),
-    ("tn fc1 wgrad", 2.0 * M * 768 * 384, 2 * (M * 768 + M * 384)),
-    ("tn fc2 wgrad", 2.0 * M * 384 * 768, 2 * (M * 384 + M * 768)),
-    ("tn out wgrad", 2.0 * M * 384 * 384, 2 * (M * 384 + M * 384)),
+    ("tn qkv wgrad", 2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384) + 4 * 28 * 1152 * 384),   # + the fp32 K-slice slabs it writes
+    ("tn fc1 wgrad", 2.0 * M * 768 * 384, 2 * (M * 768 + M * 384) + 4 * 42 * 768 * 384),
+    ("tn fc2 wgrad", 2.0 * M * 384 * 768, 2 * (M * 384 + M * 768) + 4 * 42 * 384 * 768),
+    ("tn out wgrad", 2.0 * M * 384 * 384, 2 * (M * 384 + M * 384) + 4 * 64 * 384 * 384),
 ]
 
 
@@ -89,7 +89,8 @@ def main():
     timeit(lambda: L.vg_linear_dgrad_ln_bwd(p(x768), p(w1_t), p(x384), p(mean), p(rstd), p(gam), p(res), p(o384), p(o384b), p(part), M, 768, 0.1, 1, 1, None, st), 5)
     timeit(lambda: L.vg_linear_dgrad(p(x384), p(wo), p(o384), M, 384, 384, 0, None, None, 0.0, st), 6)
     timeit(lambda: L.vg_linear_dgrad_ln_bwd(p(x1152), p(wqkv_t), p(x384), p(mean), p(rstd), p(gam), p(res), p(o384), p(o384b), p(part), M, 1152, 0.1, 1, 0, None, st), 7)
-    for i, (N, K, splits, dy, x) in enumerate([(1152, 384, 4, x1152, x384), (768, 384, 6, x768, x384), (384, 768, 6, x384, x768), (384, 384, 8, x384, x384)]):
+    # K slices so that a single problem fills the chip like the engine's grouped launch does (~252 workgroups of 128 x 384 tiles)
+    for i, (N, K, splits, dy, x) in enumerate([(1152, 384, 28, x1152, x384), (768, 384, 42, x768, x384), (384, 768, 42, x384, x768), (384, 384, 64, x384, x384)]):
         dw = torch.zeros(N, K, device="cuda"); slab = torch.empty(splits * N * K, device="cuda")
         timeit(lambda: L.vg_linear_wgrad(p(dy), p(x), p(dw), p(slab), slab.numel(), M, N, K, splits, 1, st), 8 + i)
 

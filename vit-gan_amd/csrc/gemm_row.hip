@@ -587,9 +587,12 @@ int vg_row_nwg(int M) {
   if (M < 16 || (M & 15)) return 0;
   const int units = M / 16;
 #ifndef RW_MINUNITS
-#define RW_MINUNITS 4
+#define RW_MINUNITS 2
 #endif
-  const int want = (units + RW_MINUNITS - 1) / RW_MINUNITS;  // at least ~RW_MINUNITS units per workgroup while the chip is not full
+  // at least RW_MINUNITS units per workgroup while the chip is not full.  2, not 4: the generator's launches (8 192 rows = 512
+  // units) run 2 us shorter on 256 workgroups of 2 units than on 128 of 4 - a small problem is prologue + epilogue, and both
+  // halve with the rows of a workgroup (whole step 6.06 -> 5.98 ms)
+  const int want = (units + RW_MINUNITS - 1) / RW_MINUNITS;
   return want < 256 ? want : 256;
 }
 
