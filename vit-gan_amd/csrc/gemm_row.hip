@@ -45,12 +45,14 @@ constexpr int RW_MAXMT = RW_MAXMT_;  // m-tiles per tile (tuning builds: make va
 constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
 constexpr int RW_NSLOT = 4;
 constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
-constexpr int RW_GAM = 2 * RW_E * 4;                   // behind the ring: gamma (and the SLN's bias) in fp32 - the LNBWD epilogue has no registers for them
+constexpr int RW_RED = (3 * 32 * RW_E + 16) * 4;        // LNBWD column-sum fold: [3 sums][32 row-group slots][384] fp32 (+ the SLN scalars), over the ring
+constexpr int RW_BODY = RW_RED > RW_RING ? RW_RED : RW_RING;
+constexpr int RW_GAM = 2 * RW_E * 4;                   // behind both: gamma (and the SLN's bias) in fp32 - the LNBWD epilogue has no registers for them
 constexpr int RW_TS = 784;                             // row stride of the bf16 epilogue tile (LNBWD): 768 + 16 (ds_write_b64 2-way at worst)
 constexpr int RW_TSF = 1552;                           // row stride of the fp32 epilogue tile (LNFWD, 80 rows at a time): 1536 + 16
 static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
 static_assert(80 * RW_TSF <= RW_RING, "fp32 half tile must fit the ring");
-static_assert((3 * 8 * RW_E + 16) * 4 <= RW_RING, "column-sum fold must fit the ring");
+static_assert(RW_BODY + RW_GAM <= 160 * 1024, "LDS");
 
 // row-form chunk swizzle of gemm.hip: 16-B chunk c of row r lives at position c ^ {0,2,3,1}[(r>>2)&3]
 __device__ __host__ __forceinline__ int rw_row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
@@ -87,7 +89,7 @@ __device__ __forceinline__ float rw_row16_sum(float v) {
 #endif
 template <int EPI, bool SLN>
 __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_RING + RW_GAM];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_BODY + RW_GAM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wid >> 2;  // the two waves of a SIMD are w and w + 4
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
 
   if (EPI == VG_ROW_LNBWD && tid < RW_E / 4) {  // visible to everyone behind the first tile's barriers
-    *(f32x4*)(smem + RW_RING + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
-    if (SLN) *(f32x4*)(smem + RW_RING + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.lbias + 4 * tid);
+    *(f32x4*)(smem + RW_BODY + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
+    if (SLN) *(f32x4*)(smem + RW_BODY + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.lbias + 4 * tid);
   }
   float cum_s = 0.f;               // LNBWD + SLN: threads 0 / 1 carry d gs / d bs
   float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < CH; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
-      const unsigned char* gam_lds = smem + RW_RING;
+      const unsigned char* gam_lds = smem + RW_BODY;
       float s_gs = 0.f, s_bs = 0.f;  // SLN: d gs = sum dy w (xhat gamma + lbias), d bs = sum dy w
       auto ld_f32 = [&](const unsigned char* base, int i, float (&dst)[CH]) {
 #pragma unroll
@@ -479,24 +481,28 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           }
         }
       }
-      // fold the column sums: the row groups of a wave (shuffles), then the 8 waves (LDS, over the tile), fixed order
+      // fold the column sums: every row group of every wave writes its partial row to LDS (over the tile and the ring: both are
+      // done with) and 3 x 384 threads add the 8 RPW rows of a column in a fixed order.  (The first version reduced the row groups of
+      // a wave with __shfl_xor first: 432 ds_bpermute + lgkmcnt round trips per wave, a visible part of this epilogue.)
       __syncthreads();  // the tile has been read
-      float* red = (float*)smem;  // [3][8][384] (+ 16 scalars)
+      float* red = (float*)smem;  // [3][NSL][384] (+ 16 scalars)
+      constexpr int NSL = 8 * RPW;
+      {
+        const int slot = RPW * wid + rgl;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
+          const int col = CH * (subl + LPR * i);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          float sa = ag[i][j], sb = ab[i][j], sc = ac[i][j];
-          if (LPR == 16) { sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64); sc += __shfl_xor(sc, 16, 64); }
-          sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64); sc += __shfl_xor(sc, 32, 64);
-          if (rgl == 0) {
-            const int col = CH * (subl + LPR * i) + j;
-            red[(0 * 8 + wid) * RW_E + col] = sa; red[(1 * 8 + wid) * RW_E + col] = sb; red[(2 * 8 + wid) * RW_E + col] = sc;
+          for (int q = 0; q < CH / 4; ++q) {
+            *(f32x4*)(red + (0 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ag[i][4 * q], ag[i][4 * q + 1], ag[i][4 * q + 2], ag[i][4 * q + 3]};
+            *(f32x4*)(red + (1 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ab[i][4 * q], ab[i][4 * q + 1], ab[i][4 * q + 2], ab[i][4 * q + 3]};
+            *(f32x4*)(red + (2 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ac[i][4 * q], ac[i][4 * q + 1], ac[i][4 * q + 2], ac[i][4 * q + 3]};
           }
         }
+      }
       if (SLN) {  // the two scalars: wave sums behind the column sums' region
         const float a_ = vg_wave_sum(s_gs), b_ = vg_wave_sum(s_bs);
-        if (lane == 0) { red[3 * 8 * RW_E + 2 * wid] = a_; red[3 * 8 * RW_E + 2 * wid + 1] = b_; }
+        if (lane == 0) { red[3 * NSL * RW_E + 2 * wid] = a_; red[3 * NSL * RW_E + 2 * wid + 1] = b_; }
       }
       __syncthreads();
 #pragma unroll
@@ -504,12 +510,20 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         const int c = tid + 512 * k;
         if (c < 3 * RW_E) {
           const int which = c / RW_E, col = c - which * RW_E;
-          const float* r0 = red + (which * 8) * RW_E + col;
-          cum[k] += ((r0[0] + r0[RW_E]) + (r0[2 * RW_E] + r0[3 * RW_E])) + ((r0[4 * RW_E] + r0[5 * RW_E]) + (r0[6 * RW_E] + r0[7 * RW_E]));
+          const float* r0 = red + (which * NSL) * RW_E + col;
+          float t8[8];
+#pragma unroll
+          for (int w8 = 0; w8 < 8; ++w8) {  // a wave's row groups first, then the waves pairwise: fixed association
+            float t = r0[(RPW * w8) * RW_E];
+#pragma unroll
+            for (int r = 1; r < RPW; ++r) t += r0[(RPW * w8 + r) * RW_E];
+            t8[w8] = t;
+          }
+          cum[k] += ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
         }
       }
       if (SLN && tid < 2) {
-        const float* r0 = red + 3 * 8 * RW_E + tid;
+        const float* r0 = red + 3 * NSL * RW_E + tid;
         cum_s += ((r0[0] + r0[2]) + (r0[4] + r0[6])) + ((r0[8] + r0[10]) + (r0[12] + r0[14]));
       }
     }
