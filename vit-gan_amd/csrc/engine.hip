@@ -443,6 +443,57 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   int last_side = -1;  // highest-index side event recorded by this call (for the join)
   VgFoldJobs folds; folds.n = 0;
   const size_t part_sz = (size_t)lnparts * 3 * E;
+  // Weight gradients (single-stream schedule): the blocks of this call are taken in PAIRS - the eight problems of two blocks
+  // as ONE grouped split-K launch with half the K slices (same number of workgroups: 42 tiles x 6 instead of 21 x 12), which
+  // halves the fp32 slab traffic (85 -> 42 MB written and folded per block) and the prologues / epilogues per unit of work.
+  // The launch sits in the SECOND block of the pair, in front of its last kernel (QKV input gradient + norm1 backward): that
+  // kernel writes dL/dX into the other scratch set, where the first block's fc2-gradient operand still lives.
+  const int l_hi = d.L - (stage_begin > 1 ? stage_begin : 1), l_lo = d.L - ((stage_end < d.L + 1 ? stage_end : d.L + 1) - 1);
+  const bool pairing = !ctx && want_wgrad;
+  const long long BW = 3 * E + rE + E;
+  auto wgrad_blocks = [&](int la, int nb) -> int {  // blocks la, la-1, .. (nb = 1 or 2): grouped launch + slab folds + bias partials
+    long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
+    // the slab and bslab carves hold VIT_SPLIT_CAP slices in all: never more (round 1 overran them from an environment knob)
+    // The K partition is that of a PAIR also for a block that goes alone (the odd one out, the side-stream schedule): every
+    // schedule then adds the same slices in the same order, and staged, one-shot and side-stream backward agree bit for bit.
+    int splits = pick_splits(tiles * 2, M, VIT_SPLIT_CAP / 2);
+    if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
+      splits = pick_splits384(2 * (tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn)), M, VIT_SPLIT_CAP / 2);
+#ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
+    static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
+    if (split_env > 0 && split_env <= VIT_SPLIT_CAP / 2) splits = split_env;
+#endif
+    VgGemmProb pr[8];
+    for (int j = 0; j < nb; ++j) {
+      const int lb = la - j;
+      VitWs::Set& sb = w.set[lb & 1];
+      float* slab = w.slab + (size_t)j * splits * lay.layer_weights;
+      const bf16* gb1b = drop ? sb.gm1 : sb.gmid;
+      const bf16* gb2b = drop ? sb.gm2 : sb.gin;
+      VgGemmProb* q = pr + 4 * j;
+      q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, splits);
+      q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, splits);
+      q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, splits);
+      q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, splits);
+      // bias gradients = column sums of the same dY operands: they ride along in the GEMM (ones x A on the MFMA pipe),
+      // one row per K slice, folded with the LayerNorm partials at the end.  fc2's bias: only the top block needs it
+      // here (lower blocks get it from the LN1 partials of the block above).
+      float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
+      q[0].colsum = bs; q[0].colsum_split_stride = BW;
+      q[2].colsum = bs + 3 * E; q[2].colsum_split_stride = BW;
+      if (lb == top) { q[3].colsum = bs + 3 * E + rE; q[3].colsum_split_stride = BW; }
+    }
+    VG_TRY(vg_gemm_launch(pr, 4 * nb, VG_TN, sd));
+    for (int j = 0; j < nb; ++j) {
+      const int lb = la - j;
+      const long long lob = lay.layer0 + (long long)lb * lay.layer_stride;
+      float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
+      VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, pr[4 * j].splits, G + lob, lay.layer_weights, 1, sd));
+      VG_TRY(vg_fold_push(folds, bs, pr[4 * j].splits, (int)BW, G + lob + lay.bqkv, 3 * E, G + lob + lay.b1, rE, (lb == top) ? G + lob + lay.b2 : nullptr, E,
+                          nullptr, 0));
+    }
+    return 0;
+  };
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage < stage_begin) continue;
@@ -478,6 +529,11 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     if (!rown) VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    if (pairing) {  // second block of a pair (or the odd one out at the end of this call): its and its partner's weight gradients
+      const int idx = l_hi - l;
+      if (idx & 1) VG_TRY(wgrad_blocks(l + 1, 2));
+      else if (l == l_lo) VG_TRY(wgrad_blocks(l, 1));
+    }
     // LN1 backward writes dL/dX[l] (and its masked copy for the dropout it meets next) into the OTHER set, which the
     // weight-gradient side of block l+1 may still be reading: wait for it first
     if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
@@ -496,35 +552,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
     VG_TRY(vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
-    {
-      // the four weight gradients of the block as ONE grouped split-K launch
-      const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
-      // the slab and bslab carves hold VIT_SPLIT_CAP slices: never more (round 1 overran them from an environment knob)
-      int splits = pick_splits(tiles, M, VIT_SPLIT_CAP);
-      if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
-        splits = pick_splits384(tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn), M, VIT_SPLIT_CAP);
-#ifdef VG_TUNING  // experimental builds only (make var): the product library reads no environment
-      static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
-      if (split_env > 0 && split_env <= VIT_SPLIT_CAP) splits = split_env;
-#endif
-      VgGemmProb pr[4];
-      pr[0] = wg(cur.dqkv, 3 * E, xn1, E, M, w.slab + lay.wqkv, lay.layer_weights, splits);
-      pr[1] = wg(gb1, E, ao, E, M, w.slab + lay.wo, lay.layer_weights, splits);
-      pr[2] = wg(cur.dz1, rE, xn2, E, M, w.slab + lay.w1, lay.layer_weights, splits);
-      pr[3] = wg(gb2, E, a1, rE, M, w.slab + lay.w2, lay.layer_weights, splits);
-      // bias gradients = column sums of the same dY operands: they ride along in the GEMM (ones x A on the MFMA pipe),
-      // one row per K slice, folded with the LayerNorm partials at the end.  fc2's bias: only the top block needs it
-      // here (lower blocks get it from the LN1 partials of the block above).
-      const long long BW = 3 * E + rE + E;
-      float* bs = w.bslab + (size_t)l * VIT_SPLIT_CAP * BW;
-      pr[0].colsum = bs; pr[0].colsum_split_stride = BW;
-      pr[2].colsum = bs + 3 * E; pr[2].colsum_split_stride = BW;
-      if (l == top) { pr[3].colsum = bs + 3 * E + rE; pr[3].colsum_split_stride = BW; }
-      VG_TRY(vg_gemm_launch(pr, 4, VG_TN, sd));
-      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, sd));
-      VG_TRY(vg_fold_push(folds, bs, pr[0].splits, (int)BW, G + lo + lay.bqkv, 3 * E, G + lo + lay.b1, rE, (l == top) ? G + lo + lay.b2 : nullptr, E,
-                   nullptr, 0));
-    }
+    if (!pairing) VG_TRY(wgrad_blocks(l, 1));  // side-stream schedule: block by block, behind the block's input-gradient chain
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;
       VG_TRY(vg_fold_push(folds, part1, lnparts, 3 * E, G + lo + lay.ln1_w, E, G + lo + lay.ln1_b, E, b2_prev, E, nullptr, 0));

@@ -50,7 +50,7 @@ struct VgGemmProb {
   int tiles_m, tiles_n, tile_start, k_per_split;
 };
 
-#define VG_MAX_GROUP 4
+#define VG_MAX_GROUP 8   // round 3: the weight gradients of TWO encoder blocks go out as one launch
 struct VgGemmGroup {
   int n;
   int tpw, total;     // consecutive tiles per workgroup; number of tiles of the launch
