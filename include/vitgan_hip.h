@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 5
+#define VG_ABI_VERSION 6
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -42,10 +42,15 @@ int vg_abi_version(void);
 int vg_linear_fwd(const void* A, const void* W, const float* bias, const void* res, void* C,
                   void* pre_bf16, float* pre_f32, int M, int N, int K, int act, float act_scale,
                   void* stream);
+/* fc1 of the encoder MLP as the engine runs it (src/v2/modules.py:128-139: Linear -> nn.GELU):  C = gelu(A W^T + bias) in bf16,
+ * and dcode[M,N] = gelu'(A W^T + bias) as ONE BYTE per element: code = round(200 g) + 27 (27 <-> 0 and 227 <-> 1 exactly,
+ * |error| <= 0.0025 over gelu's derivative range [-0.129, 1.129]) - all the backward keeps of the pre-activation.  N % 8 == 0. */
+int vg_linear_gelu_fwd(const void* A, const void* W, const float* bias, void* C, void* dcode, int M, int N, int K,
+                       void* stream);
 /* input gradient of nn.Linear:  dX[M,K] = dY[M,N] @ W[N,K]   (autograd of F.linear)
  * mul_mode 0: none; 4: dX *= gelu'(Z) with Z bf16 [M,K]; 5: dX *= s*cos(s*Zf), Zf fp32 [M,K];
  * 6: dX *= 1 - Z^2 (Z = tanh output, bf16 [M,K]); 7: dX *= Z (Z = a derivative the forward stored, bf16 [M,K]:
- * what the engine's fc2 input gradient uses with the gelu' its fc1 epilogue wrote). */
+ * 8: dX *= decode(Z), Z the byte codes [M,K] written by vg_linear_gelu_fwd - what the engine's fc2 input gradient uses). */
 int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode,
                     const void* Z, const float* Zf, float act_scale, void* stream);
 /* weight gradient of nn.Linear:  dW[N,K] (+)= dY[M,N]^T @ X[M,K], computed as `splits` slices of M

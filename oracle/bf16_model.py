@@ -11,7 +11,7 @@ parameters, the fp32 gradient of the modulation vector stay fp32), forward and b
 
   * GEMM operands: activations as stored (bf16), weights = the bf16 shadow of the fp32 master (gradient passes straight
     through to the master);
-  * every activation the forward stores: X[l], LN/SLN outputs, qkv, attention output, x_mid, gelu(.) and gelu'(.),
+  * every activation the forward stores: X[l], LN/SLN outputs, qkv, attention output, x_mid, gelu(.) and gelu'(.) (the derivative as one byte, grid 1/200),
     tanh(.), sin(.) ; the unnormalised softmax numerator is rounded before P.V (the kernels feed the exponentiated
     accumulators to the MFMA as bf16), the denominator is the fp32 row sum;
   * every gradient tensor the backward stores: dL/dX[l], the LN-input gradients, d qkv, d(attention out), d z1 (after the
@@ -85,14 +85,18 @@ class _Drop(torch.autograd.Function):
 
 
 class _GeluStore(torch.autograd.Function):
-    """fc1 epilogue (gemm.hip ACT_GELU with c2_gelu_grad): stores bf16 gelu(pre) AND bf16 gelu'(pre); the fc2 dgrad
-    epilogue multiplies its fp32 accumulator by the stored derivative and stores bf16 (VG_ACT_MUL_Z)."""
+    """fc1 epilogue (gemm.hip / gemm_wr.hip ACT_GELU with c2_gelu_grad = 2): stores bf16 gelu(pre) AND gelu'(pre) as one byte per
+    element on the grid k/200 (code = round(200 g) + 27, vg_common.h vg_g8_pack4); the fc2 dgrad epilogue multiplies its fp32
+    accumulator by the decoded derivative and stores bf16 (VG_ACT_MUL_Z8)."""
 
     @staticmethod
     def forward(ctx, pre):
         phi = 0.5 * (1.0 + torch.erf(pre * 0.7071067811865476))
         gd = phi + pre * 0.3989422804014327 * torch.exp(-0.5 * pre * pre)
-        ctx.save_for_backward(bf(gd))
+        if _ROUND:
+            code = torch.clamp(torch.round(gd * 200.0 + 27.0), 0.0, 255.0)
+            gd = (code - 27.0) * 0.005
+        ctx.save_for_backward(gd)
         return bf(pre * phi)
 
     @staticmethod

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vitgan_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert set(_lib._SIGNATURES) <= set(names), set(_lib._SIGNATURES) - set(names)
-    assert lib.vg_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.vg_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_argument_validation_without_gpu():
@@ -38,6 +38,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.lib()
     assert lib.vg_attention_fwd(None, None, None, 1, 1, 1, 32, 1.0, None) == -1
     assert lib.vg_linear_fwd(None, None, None, None, None, None, None, 8, 8, 8, 0, 0.0, None) == -1
+    assert lib.vg_linear_gelu_fwd(None, None, None, None, None, 8, 8, 8, None) == -1
     # full-row Linear + LayerNorm entry points (csrc/gemm_row.hip): host-side shape queries and null checks
     assert lib.vg_row_parts(33280) == 256 and lib.vg_row_parts(16640) == 256 and lib.vg_row_parts(2080) == 65 and lib.vg_row_parts(130) == 0
     assert lib.vg_row_pack_elems(384) == 384 * 384 and lib.vg_row_pack_elems(40) == -2

@@ -75,6 +75,59 @@ def test_linear_gelu_fwd_weights_in_registers(M, N):
     u.assert_close(out, F.gelu(pre), BF_TOL, "gelu")
 
 
+def _gelu_grad(pre):
+    return 0.5 * (1.0 + torch.erf(pre * 0.7071067811865476)) + pre * 0.3989422804014327 * torch.exp(-0.5 * pre * pre)
+
+
+# (1312, 768) and (16640, 1536) run on gemm_wr.hip (K = 384), the others on the tiled kernel (gemm.hip): producer and consumer of
+# the one-byte derivative code have to agree across the two kernels
+@pytest.mark.parametrize("M,N,K", [(1312, 768, 384), (16640, 1536, 384), (130, 768, 192), (260, 2048, 512), (77, 96, 768)])
+def test_linear_gelu_fwd_byte_derivative(M, N, K):
+    """fc1 as the engine runs it: bf16 gelu(pre) + gelu'(pre) as ONE BYTE per element, code = round(200 g) + 27 (exact at 0 and 1);
+    decoded it is within half a grid step (0.0025) of the fp32 derivative, plus what the accumulation order moves near a rounding
+    boundary (one more step)."""
+    u = _u()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = u.rbf(torch.randn(M, K, generator=g) * 1.5)
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    pre = A @ W.t() + b
+    dA, dW, db = u.dev(A, u.BF), u.dev(W, u.BF), u.dev(b)
+    out = torch.full((M + 8, N), 7.0, dtype=u.BF, device="cuda")
+    code = torch.full((M + 8, N), 255, dtype=torch.uint8, device="cuda")
+    u.call("vg_linear_gelu_fwd", u.ptr(dA), u.ptr(dW), u.ptr(db), u.ptr(out), u.ptr(code), M, N, K, u.stream())
+    u.sync()
+    u.assert_close(out[:M], F.gelu(pre), BF_TOL, "gelu")
+    assert bool((out[M:] == 7.0).all()) and bool((code[M:] == 255).all()), "rows beyond M were written"
+    dec = (code[:M].cpu().float() - 27.0) * 0.005
+    ref = _gelu_grad(pre)
+    err = (dec - ref).abs()
+    assert float(err.max()) <= 0.0025 + 0.005, float(err.max())
+    assert float((err > 0.00251).float().mean()) < 2e-3  # off-by-one codes only where the fp32 sum sits on a rounding boundary
+    assert float(err.mean()) < 0.0014                    # uniform rounding on a grid of 0.005: mean |error| = 0.00125
+    sat = pre.abs() > 6.0
+    if bool(sat.any()):  # saturated units: the derivative is exactly 0 or 1
+        assert torch.equal(dec[sat], (pre[sat] > 0).float())
+    assert int(code[:M].min()) >= 1 and int(code[:M].max()) <= 253
+
+
+@pytest.mark.parametrize("M,K,N", [(1312, 768, 384), (33280, 1536, 384), (130, 768, 192), (260, 2048, 512), (100, 96, 768)])
+def test_linear_dgrad_byte_derivative(M, K, N):
+    """fc2 input gradient times the decoded one-byte derivative (mul_mode 8), on both kernels."""
+    u = _u()
+    g = torch.Generator().manual_seed(M + 5 * K + N)
+    dY = u.rbf(torch.randn(M, N, generator=g))
+    W = u.rbf(torch.randn(N, K, generator=g) / math.sqrt(N))
+    code = torch.randint(1, 254, (M, K), generator=g, dtype=torch.int32).to(torch.uint8)
+    ref = (dY @ W) * ((code.float() - 27.0) * 0.005)
+    out = torch.full((M + 64, K), 7.0, dtype=u.BF, device="cuda")
+    ddY, dW_, dcode = u.dev(dY, u.BF), u.dev(W, u.BF), code.cuda()
+    u.call("vg_linear_dgrad", u.ptr(ddY), u.ptr(dW_), u.ptr(out), M, N, K, 8, u.ptr(dcode), None, 0.0, u.stream())
+    u.sync()
+    u.assert_close(out[:M], ref, BF_TOL, "dX")
+    assert bool((out[M:] == 7.0).all()), "rows beyond M were written"
+
+
 @pytest.mark.parametrize("M,N", WR_SHAPES)
 @pytest.mark.parametrize("res", [False, True])
 def test_linear_fwd_weights_in_registers(M, N, res):

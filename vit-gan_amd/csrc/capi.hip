@@ -16,11 +16,18 @@ extern "C" int vg_linear_fwd(const void* A, const void* W, const float* bias, co
   p.act = act; p.act_scale = act_scale;
   return vg_gemm_launch(&p, 1, VG_NT, (hipStream_t)stream);
 }
+extern "C" int vg_linear_gelu_fwd(const void* A, const void* W, const float* bias, void* C, void* dcode, int M, int N, int K, void* stream) {
+  if (!A || !W || !C || !dcode) return -1;
+  VgGemmProb p = vg_gemm_prob();
+  p.A = (const bf16*)A; p.lda = K; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = N; p.K = K;
+  p.C = (bf16*)C; p.ldc = N; p.bias = bias; p.C2 = (bf16*)dcode; p.ldc2 = N; p.c2_gelu_grad = 2; p.act = VG_ACT_GELU;
+  return vg_gemm_launch(&p, 1, VG_NT, (hipStream_t)stream);
+}
 extern "C" int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K, int mul_mode, const void* Z,
                                const float* Zf, float act_scale, void* stream) {
   if (!dY || !W || !dX) return -1;
-  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS && mul_mode != VG_ACT_MUL_TANH_GRAD && mul_mode != VG_ACT_MUL_Z) return -4;
-  if (((mul_mode == VG_ACT_MUL_GELU_GRAD || mul_mode == VG_ACT_MUL_TANH_GRAD || mul_mode == VG_ACT_MUL_Z) && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
+  if (mul_mode != 0 && mul_mode != VG_ACT_MUL_GELU_GRAD && mul_mode != VG_ACT_MUL_COS && mul_mode != VG_ACT_MUL_TANH_GRAD && mul_mode != VG_ACT_MUL_Z && mul_mode != VG_ACT_MUL_Z8) return -4;
+  if (((mul_mode == VG_ACT_MUL_GELU_GRAD || mul_mode == VG_ACT_MUL_TANH_GRAD || mul_mode == VG_ACT_MUL_Z || mul_mode == VG_ACT_MUL_Z8) && !Z) || (mul_mode == VG_ACT_MUL_COS && !Zf)) return -1;
   VgGemmProb p = vg_gemm_prob();
   p.A = (const bf16*)dY; p.lda = N; p.B = (const bf16*)W; p.ldb = K; p.M = M; p.N = K; p.K = N;
   p.C = (bf16*)dX; p.ldc = K; p.act = mul_mode; p.act_scale = act_scale;

@@ -214,7 +214,8 @@ static int pick_splits384(long long tiles, int Krows, int cap) {
 #define VIT_SPLIT_CAP 12
 #define EMB_SPLIT_CAP 32
 struct VitWs {
-  bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *z1, *a1, *xcls, *hcls, *th;
+  bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *a1, *xcls, *hcls, *th;
+  unsigned char* z1;  // gelu'(fc1 pre-activation), one byte per element (vg_common.h vg_g8_pack4)
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf;
   // backward scratch, one set per block parity (block l uses set l&1; its LN1 backward writes gin/gm2 of set (l-1)&1):
   // the weight-gradient side of block l still reads set l&1 while the main stream works on block l-1 in the other set
@@ -240,7 +241,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   w.ao = c.take<bf16>(L * M * E);
   w.xmid = c.take<bf16>(L * M * E);
   w.xn2 = c.take<bf16>(L * M * E);
-  w.z1 = c.take<bf16>(L * M * rE);
+  w.z1 = c.take<unsigned char>(L * M * rE);
   w.a1 = c.take<bf16>(L * M * rE);
   w.xcls = c.take<bf16>(B * E); w.hcls = c.take<bf16>(B * E); w.th = c.take<bf16>(B * E);
   w.lse = c.take<float>(L * (long long)B * d.H * S);
@@ -348,7 +349,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     bf16* ao = w.ao + (size_t)l * ME;
     bf16* xmid = w.xmid + (size_t)l * ME;
     bf16* xn2 = w.xn2 + (size_t)l * ME;
-    bf16* z1 = w.z1 + (size_t)l * M * rE;
+    unsigned char* z1 = w.z1 + (size_t)l * M * rE;
     bf16* a1 = w.a1 + (size_t)l * M * rE;
     const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
     // norm1: standalone for block 0 (and on the tiled path); on the full-row path the fc2 epilogue of block l-1 wrote it
@@ -365,8 +366,8 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
       VG_TRY(vg_ln_fwd_launch(xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, xn2, E, w.mean2 + (size_t)l * M,
                               w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
     }
-    // z1 keeps gelu'(pre-activation), the only thing the backward needs of it
-    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, z1, nullptr, st, nullptr, 0, 1));
+    // z1 keeps gelu'(pre-activation), the only thing the backward needs of it, as one byte per element
+    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, (bf16*)z1, nullptr, st, nullptr, 0, 2));
     if (rown) {  // X[l+1] = x_mid + drop(fc2(a1)) and the NEXT block's norm1 of it (the last block's output only feeds the CLS rows)
       const bool nx = l + 1 < d.L;
       const long long ln = lo + lay.layer_stride;
@@ -505,7 +506,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* ao = w.ao + (size_t)l * ME;
     const bf16* xmid = w.xmid + (size_t)l * ME;
     const bf16* xn2 = w.xn2 + (size_t)l * ME;
-    const bf16* z1 = w.z1 + (size_t)l * M * rE;
+    const unsigned char* z1 = w.z1 + (size_t)l * M * rE;
     const bf16* a1 = w.a1 + (size_t)l * M * rE;
     VitWs::Set& cur = w.set[l & 1];
     VitWs::Set& nxt = w.set[(l & 1) ^ 1];  // receives dL/dX[l] for block l-1
@@ -515,7 +516,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
     // ---------------- input-gradient chain (main stream) ----------------
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
-    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z, z1, nullptr, 0.f, st));
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
     const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
     if (rown) {  // fc1 input gradient + norm2 backward + the residual-stream gradient
       VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid,

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   // odd lane-groups the odd one), so each lane loads/stores 16 B (bf16) or 32 B (fp32) per slot with no trip
   // through LDS (the LDS transpose of the first version cost ~1.5k LDS cycles per workgroup and stalled the
   // co-resident workgroup's main loop).  8 slots per lane: q = 2*mt + pair.
-  constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD || ACT == VG_ACT_MUL_Z);
+  constexpr bool NEED_ZBF = (ACT == VG_ACT_MUL_GELU_GRAD || ACT == VG_ACT_MUL_TANH_GRAD || ACT == VG_ACT_MUL_Z || ACT == VG_ACT_MUL_Z8);
+  constexpr bool Z8 = (ACT == VG_ACT_MUL_Z8);
   constexpr bool NEED_ZF = (ACT == VG_ACT_MUL_COS);
   constexpr bool HAS_RES = (FEAT & F_RES) != 0, HAS_RESF = (FEAT & F_RESF) != 0, HAS_REMAP = (FEAT & F_REMAP) != 0;
   constexpr bool HAS_C2 = (FEAT & F_C2) != 0, HAS_PREF32 = (FEAT & F_PREF32) != 0, HAS_DROP = (FEAT & F_DROP) != 0;
@@ -423,7 +424,12 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       const bool ok = n < eN && m < eM;
       if (PRE_BF) {
         bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
+        if (Z8) {  // 8 bytes per lane: the codes of its 8 columns, carried in the first half of the slot
+          u32x2 c8 = {0u, 0u};
+          if (ok) c8 = *(const u32x2*)((const unsigned char*)eZ + (unsigned)(m * eldz + n));
+          union { u32x4 u; bf16x8 b; } cv; cv.u = (u32x4){c8[0], c8[1], 0u, 0u};
+          zb = cv.b;
+        } else if (NEED_ZBF) { if (ok) zb = *(const bf16x8*)(eZ + (unsigned)(m * eldz + n)); }
         else if (eres && ok) zb = *(const bf16x8*)(eres + (unsigned)(out_row(m) * eldr + n));
         pre_bf[qq] = zb;
       }
@@ -475,10 +481,15 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
 #pragma unroll
         for (int r = 0; r < 8; ++r) vg_gelu_both(v[r], gact[r], gd[r]);
         if (HAS_C2 && eC2) {
-          bf16x8 o;
+          if (ec2g == 2) {
+            const u32x2 c8 = {vg_g8_pack4(gd[0], gd[1], gd[2], gd[3]), vg_g8_pack4(gd[4], gd[5], gd[6], gd[7])};
+            *(u32x2*)((unsigned char*)eC2 + (unsigned)(mo * eldc2 + n)) = c8;
+          } else {
+            bf16x8 o;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(ec2g ? gd[r] : v[r]);
-          *(bf16x8*)(eC2 + (unsigned)(mo * eldc2 + n)) = o;
+            for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(ec2g ? gd[r] : v[r]);
+            *(bf16x8*)(eC2 + (unsigned)(mo * eldc2 + n)) = o;
+          }
         }
       } else if (HAS_C2 && eC2) {
         bf16x8 o;
@@ -486,7 +497,11 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
         for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
         *(bf16x8*)(eC2 + (unsigned)(mo * eldc2 + n)) = o;
       }
-      if (NEED_ZBF) {
+      if (Z8) {
+        union { bf16x8 b; u32x4 u; } cv; cv.b = pre_bf[PRE_BF ? qq : 0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] *= vg_g8_value(cv.u[0], r); v[r + 4] *= vg_g8_value(cv.u[1], r); }
+      } else if (NEED_ZBF) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const float zv = vg_bf2f(pre_bf[PRE_BF ? qq : 0][r]);
@@ -579,7 +594,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     constexpr long long t4min = 96;
 #endif
     // epilogues that fit the 128-register budget of 8-wave workgroups (sin / cos / tanh variants do not)
-    const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z || probs[i].act == VG_ACT_GELU;
+    const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z || probs[i].act == VG_ACT_MUL_Z8 || probs[i].act == VG_ACT_GELU;
     if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;
   }
 #ifdef VG_TUNING
@@ -605,6 +620,9 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
     if (mode == VG_NT && (p.K & 7)) return -3;
     if (mode == VG_NN && (p.K & 7)) return -3;
     if (mode == VG_TN && (p.M & 7)) return -3;
+    // one-byte derivative codes: 8-byte accesses per lane
+    if (p.c2_gelu_grad == 2 && p.C2 && (p.act != VG_ACT_GELU || (p.ldc2 & 7))) return -3;
+    if (p.act == VG_ACT_MUL_Z8 && (!p.Z || (p.ldz & 7))) return -3;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + BN - 1) / BN;
     int splits = (mode == VG_TN) ? (p.splits > 0 ? p.splits : 1) : 1;
@@ -684,6 +702,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
       case VG_ACT_MUL_COS: VG_BY_WM(VG_NN, VG_ACT_MUL_COS, 0); break;
       case VG_ACT_MUL_TANH_GRAD: VG_BY_WM(VG_NN, VG_ACT_MUL_TANH_GRAD, 0); break;
       case VG_ACT_MUL_Z: VG_BY_WM(VG_NN, VG_ACT_MUL_Z, 0); break;
+      case VG_ACT_MUL_Z8: VG_BY_WM(VG_NN, VG_ACT_MUL_Z8, 0); break;
       default: return -4;
     }
   } else if (mode == VG_TN) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
 
   // ---- epilogue operands, read from kernarg memory once -----------------------------------------------------------
   constexpr bool HAS_RES = (FEAT & WF_RES) != 0, HAS_C2 = (FEAT & WF_C2) != 0, HAS_DROP = (FEAT & WF_DROP) != 0;
-  constexpr bool NEED_Z = (ACT == VG_ACT_MUL_Z);
+  constexpr bool NEED_Z = (ACT == VG_ACT_MUL_Z || ACT == VG_ACT_MUL_Z8), Z8 = (ACT == VG_ACT_MUL_Z8);
   bf16* const eC = P.C; const int eldc = P.ldc;
   bf16* const eC2 = P.C2; const int eldc2 = P.ldc2; const int ec2g = P.c2_gelu_grad;
   const float* const ebias = P.bias;
@@ -284,7 +284,12 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
         for (int qq = 0; qq < GS; ++qq) {
           const int m = m0 + 16 * (GS * h + qq) + li;
           bf16x8 zb = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (eres && m < eM) zb = *(const bf16x8*)(eres + (unsigned)(m * eldr + ncol));
+          if (Z8) {  // 8 bytes per lane: the codes of its 8 columns, carried in the first half of the slot
+            u32x2 c8 = {0u, 0u};
+            if (eres && m < eM) c8 = *(const u32x2*)((const unsigned char*)eres + (unsigned)(m * eldr + ncol));
+            union { u32x4 u; bf16x8 b; } cv; cv.u = (u32x4){c8[0], c8[1], 0u, 0u};
+            zb = cv.b;
+          } else if (eres && m < eM) zb = *(const bf16x8*)(eres + (unsigned)(m * eldr + ncol));
           pre[qq] = zb;
         }
       }
@@ -306,10 +311,15 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
 #pragma unroll
           for (int r = 0; r < 8; ++r) vg_gelu_both(v[r], ga[r], gd[r]);
           if (HAS_C2 && eC2) {
-            bf16x8 o;
+            if (ec2g == 2) {
+              const u32x2 c8 = {vg_g8_pack4(gd[0], gd[1], gd[2], gd[3]), vg_g8_pack4(gd[4], gd[5], gd[6], gd[7])};
+              *(u32x2*)((unsigned char*)eC2 + (unsigned)(m * eldc2 + ncol)) = c8;
+            } else {
+              bf16x8 o;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(ec2g ? gd[r] : v[r]);
-            *(bf16x8*)(eC2 + (unsigned)(m * eldc2 + ncol)) = o;
+              for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(ec2g ? gd[r] : v[r]);
+              *(bf16x8*)(eC2 + (unsigned)(m * eldc2 + ncol)) = o;
+            }
           }
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] = ga[r];
@@ -319,7 +329,11 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
           for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
           *(bf16x8*)(eC2 + (unsigned)(m * eldc2 + ncol)) = o;
         }
-        if (NEED_Z) {
+        if (Z8) {
+          union { bf16x8 b; u32x4 u; } cv; cv.b = pre[qq];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] *= vg_g8_value(cv.u[0], r); v[r + 4] *= vg_g8_value(cv.u[1], r); }
+        } else if (NEED_Z) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] *= vg_bf2f(pre[qq][r]);
         }
@@ -363,7 +377,7 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
   int ldmax = p.N > p.ldc ? p.N : p.ldc;
   if (p.res) { if (p.ldr & 7) return 0; if (p.ldr > ldmax) ldmax = p.ldr; }
   if (p.C2) { if (p.ldc2 & 7) return 0; if (p.ldc2 > ldmax) ldmax = p.ldc2; }
-  if (p.act == VG_ACT_MUL_Z) { if (!p.Z || (p.ldz & 7)) return 0; if (p.ldz > ldmax) ldmax = p.ldz; }
+  if (p.act == VG_ACT_MUL_Z || p.act == VG_ACT_MUL_Z8) { if (!p.Z || (p.ldz & 7)) return 0; if (p.ldz > ldmax) ldmax = p.ldz; }
   if ((long long)(p.M + 128) * (long long)ldmax >= (1LL << 31)) return 0;
   if ((long long)p.M * p.lda * 2 >= (1LL << 32)) return 0;  // 32-bit lane offsets inside a tile only, but keep A itself addressable
   int feat = 0;
@@ -395,6 +409,7 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
     if (feat != 0) return 0;
     if (p.act == VG_ACT_NONE) WR_LAUNCH(1, VG_ACT_NONE, 0);  // Z / Zf are only read by the activations that name them
     else if (p.act == VG_ACT_MUL_Z && p.Z) WR_LAUNCH(1, VG_ACT_MUL_Z, 0);
+    else if (p.act == VG_ACT_MUL_Z8 && p.Z) WR_LAUNCH(1, VG_ACT_MUL_Z8, 0);
     else return 0;
   }
 #undef WR_LAUNCH

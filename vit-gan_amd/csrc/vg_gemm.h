@@ -17,6 +17,7 @@ enum {
   VG_ACT_MUL_COS = 5,        // v *= act_scale*cos(act_scale*Zf[m,n])  (SIREN dgrad epilogue)
   VG_ACT_MUL_TANH_GRAD = 6,  // v *= 1 - Z[m,n]^2, Z = tanh output  (classifier fc2 dgrad epilogue)
   VG_ACT_MUL_Z = 7,          // v *= Z[m,n]: Z = a derivative stored by the forward (see c2_gelu_grad)
+  VG_ACT_MUL_Z8 = 8,         // v *= decode(Z8[m,n]): the derivative as one byte per element (c2_gelu_grad = 2; Z points at bytes, ldz in bytes)
 };
 
 struct VgGemmProb {
@@ -30,7 +31,9 @@ struct VgGemmProb {
   int cf_accumulate;           // TN with ONE K slice: Cf += result (the gradient buffer itself; no slab, no fold pass)
   bf16* C2; int ldc2;          // bf16 pre-activation copy (nullable)
   int c2_gelu_grad;            // with VG_ACT_GELU: C2 receives gelu'(pre-activation) instead of the pre-activation itself -
-                               // all the backward needs of it, and the fc2 dgrad epilogue becomes one multiply (VG_ACT_MUL_Z)
+                               // all the backward needs of it, and the fc2 dgrad epilogue becomes one multiply (VG_ACT_MUL_Z).
+                               // 2: the derivative as ONE BYTE per element (vg_g8_pack4, vg_common.h): C2 points at bytes, ldc2 in bytes,
+                               // ldc2 % 8 == 0; read back by VG_ACT_MUL_Z8
   const float* bias;           // [N] fp32 (nullable)
   const bf16* res; int ldr;    // residual added after the activation (nullable)
   const float* resf; int res_period;  // fp32 addend table [res_period, N] indexed by m % res_period
