@@ -133,10 +133,11 @@ def step_roofline(torch, B, reps=30):
     x384, x768, x1152, res = rnd(M, 384), rnd(M, 768), rnd(M, 1152), rnd(M, 384)
     gam, bet, bias = torch.ones(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
     mean, rstd = torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")
-    o384, o384b, o768, o768b, o1152 = (torch.empty(M, n, device="cuda", dtype=BF) for n in (384, 384, 768, 768, 1152))
+    o384, o384b, o768, o1152 = (torch.empty(M, n, device="cuda", dtype=BF) for n in (384, 384, 768, 1152))
     wqkv, w1, w2 = rnd(1152, 384, s=0.05), rnd(768, 384, s=0.05), rnd(384, 768, s=0.05)
     wqkv_t, w2_p = packed(wqkv, 1152, 1), packed(w2, 768, 0)
     b768 = torch.zeros(768, device="cuda")
+    code = torch.empty(M, 768, device="cuda", dtype=torch.uint8)
     part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
     lse = torch.zeros(2 * B * 4 * 65, device="cuda")
     dw = torch.zeros(1152, 384, device="cuda")
@@ -162,9 +163,9 @@ def step_roofline(torch, B, reps=30):
         ("vg_attn_bwd_kernel<96,5>: fused attention backward, one workgroup per (image, head)", [2 * B, H, S, HE],
          lambda: chk(L.vg_attention_bwd(p(x1152), p(x384), p(res), p(lse), p(o1152), 2 * B, H, S, HE, 1.0 / HE ** 0.5, st), "vg_attention_bwd"),
          10.0 * 2 * B * H * S * S * HE, 2 * (M * 1152 * 2 + M * 384 * 2) + 4 * 2 * B * H * S, None),
-        ("vg_gemm_wr_kernel<0,1,2>: fc1 + GELU, second output for the backward", [M, 768, 384],
-         lambda: chk(L.vg_linear_fwd(p(x384), p(w1), p(b768), None, p(o768), p(o768b), None, M, 768, 384, 1, 0.0, st), "vg_linear_fwd"),
-         2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + 2 * M * 768), "wr fc1+gelu+2nd out"),
+        ("vg_gemm_wr_kernel<0,1,2>: fc1 + GELU, gelu' for the backward as one byte per element", [M, 768, 384],
+         lambda: chk(L.vg_linear_gelu_fwd(p(x384), p(w1), p(b768), p(o768), p(code), M, 768, 384, st), "vg_linear_gelu_fwd"),
+         2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + M * 768) + M * 768, "wr fc1+gelu+gelu' bytes"),
     ]
     traffic = {}
     try:

@@ -6,9 +6,9 @@ Run under rocprofv3 for PMC (tools/pmc_traffic.py recovers the shapes by positio
   name                         entry point                  kernel
   wr qkv fwd                   vg_linear_fwd                vg_gemm_wr_kernel<0,0,0>
   row out+res+ln fwd           vg_linear_ln_fwd  (K=384)    vg_gemm_row_kernel<0>
-  wr fc1+gelu+2nd out          vg_linear_fwd act=1 + pre    vg_gemm_wr_kernel<0,1,2>
+  wr fc1+gelu+gelu' bytes      vg_linear_gelu_fwd           vg_gemm_wr_kernel<0,1,2>
   row fc2+res+ln fwd           vg_linear_ln_fwd  (K=768)    vg_gemm_row_kernel<0>
-  wr fc2 dgrad*stored          vg_linear_dgrad mul=7        vg_gemm_wr_kernel<1,7,0>
+  wr fc2 dgrad*stored          vg_linear_dgrad mul=8        vg_gemm_wr_kernel<1,8,0>
   row fc1 dgrad+ln bwd         vg_linear_dgrad_ln_bwd K=768 vg_gemm_row_kernel<1>
   wr out dgrad                 vg_linear_dgrad              vg_gemm_wr_kernel<1,0,0>
   row qkv dgrad+ln bwd         vg_linear_dgrad_ln_bwd K=1152 vg_gemm_row_kernel<1>
@@ -25,9 +25,9 @@ M = int(os.environ.get("M", B * 65))
 SHAPES = [
     ("wr qkv fwd", 2.0 * M * 1152 * 384, 2 * (M * 384 + 1152 * 384 + M * 1152)),
     ("row out+res+ln fwd", 2.0 * M * 384 * 384, 2 * (M * 384 + 384 * 384 + 3 * M * 384) + 8 * M),
-    ("wr fc1+gelu+2nd out", 2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + 2 * M * 768)),
+    ("wr fc1+gelu+gelu' bytes", 2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + M * 768) + M * 768),  # gelu' as one byte per element
     ("row fc2+res+ln fwd", 2.0 * M * 384 * 768, 2 * (M * 768 + 384 * 768 + 3 * M * 384) + 8 * M),
-    ("wr fc2 dgrad*stored", 2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + 2 * M * 768)),
+    ("wr fc2 dgrad*stored", 2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + M * 768) + M * 768),
     ("row fc1 dgrad+ln bwd", 2.0 * M * 384 * 768, 2 * (M * 768 + 384 * 768 + 4 * M * 384) + 8 * M),
     ("wr out dgrad", 2.0 * M * 384 * 384, 2 * (M * 384 + 384 * 384 + M * 384)),
     ("row qkv dgrad+ln bwd", 2.0 * M * 384 * 1152, 2 * (M * 1152 + 384 * 1152 + 4 * M * 384) + 8 * M),
@@ -83,9 +83,10 @@ def main():
     part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
     timeit(lambda: L.vg_linear_fwd(p(x384), p(wqkv), p(b1152), None, p(o1152), None, None, M, 1152, 384, 0, 0.0, st), 0)
     timeit(lambda: L.vg_linear_ln_fwd(p(x384), p(wo_p), p(bias384), p(res), p(o384), p(o384b), p(mean), p(rstd), p(gam), p(bet), M, 384, 1e-5, 0.1, 1, 1, None, st), 1)
-    timeit(lambda: L.vg_linear_fwd(p(x384), p(w1), p(b768), None, p(o768), p(o768b), None, M, 768, 384, 1, 0.0, st), 2)
+    code = torch.empty(M, 768, device="cuda", dtype=torch.uint8)
+    timeit(lambda: L.vg_linear_gelu_fwd(p(x384), p(w1), p(b768), p(o768), p(code), M, 768, 384, st), 2)
     timeit(lambda: L.vg_linear_ln_fwd(p(x768), p(w2_p), p(bias384), p(res), p(o384), p(o384b), p(mean), p(rstd), p(gam), p(bet), M, 768, 1e-5, 0.1, 1, 2, None, st), 3)
-    timeit(lambda: L.vg_linear_dgrad(p(x384), p(w2), p(o768), M, 384, 768, 7, p(x768), None, 0.0, st), 4)
+    timeit(lambda: L.vg_linear_dgrad(p(x384), p(w2), p(o768), M, 384, 768, 8, p(code), None, 0.0, st), 4)
     timeit(lambda: L.vg_linear_dgrad_ln_bwd(p(x768), p(w1_t), p(x384), p(mean), p(rstd), p(gam), p(res), p(o384), p(o384b), p(part), M, 768, 0.1, 1, 1, None, st), 5)
     timeit(lambda: L.vg_linear_dgrad(p(x384), p(wo), p(o384), M, 384, 384, 0, None, None, 0.0, st), 6)
     timeit(lambda: L.vg_linear_dgrad_ln_bwd(p(x1152), p(wqkv_t), p(x384), p(mean), p(rstd), p(gam), p(res), p(o384), p(o384b), p(part), M, 1152, 0.1, 1, 0, None, st), 7)

@@ -429,6 +429,161 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
   }
 }
 
+// The same backward with TWO LDS images instead of four (dot-product scores, S > 32): phase A needs K and V whole and only this
+// wave's 16 rows of Q and dO (read straight from global as fragments), phase B needs Q and dO whole and only this wave's rows of K
+// and V (fragments taken from the images before they are overwritten) - so Q and dO are staged into the SAME two images between
+// the phases.  37 KB instead of 74 KB of LDS per workgroup: four workgroups (20 waves) per CU instead of two, and it is the
+// co-resident workgroups that overlap one another's load / compute / store phases (the kernel is latency-bound: 4.0 TB/s of its
+// 205 MB at two workgroups per CU).  HBM bytes are unchanged (the fragment reads of the own rows hit L2 or are the first touch of
+// lines the second staging then finds there).  Arithmetic and operand values are those of vg_attn_bwd_kernel: results are bit-equal.
+#ifndef VG_ATTN_BWD2_WPE
+#define VG_ATTN_BWD2_WPE 5  // waves per SIMD the register budget is set for: 5 = four 5-wave workgroups per CU (96 VGPRs)
+#endif
+template <int HE, int NT, bool FP8>
+__global__ __launch_bounds__(64 * NT, VG_ATTN_BWD2_WPE) void vg_attn_bwd2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                  const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                                  bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                                  const void* __restrict__ zeros) {
+  constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
+  constexpr int IMG = RP * HE * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * IMG + 2 * RP * 4];
+  unsigned char* s0 = sm;        // K, then Q
+  unsigned char* s1 = sm + IMG;  // V, then dO
+  float* dl = (float*)(sm + 2 * IMG);  // delta[q] = sum_d dO*O
+  float* ll = dl + RP;                 // lse[q]
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
+  const int g = lane >> 4, li = lane & 15;
+  const int E = H * HE;
+  const size_t ld = 3 * (size_t)E;
+  const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
+  const bf16* kb = qb + E;
+  const bf16* vb = qb + 2 * E;
+  const bf16* ob = o + (size_t)b * S * E + h * HE;
+  const bf16* dob = d_o + (size_t)b * S * E + h * HE;
+  const float* lb = lse + ((size_t)b * H + h) * S;
+  bf16* dqb = dqkv + (size_t)b * S * ld + h * HE;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  dma_head<HE, NT>(s0, kb, ld, S, RP, zeros, wv, lane);
+  dma_head<HE, NT>(s1, vb, ld, S, RP, zeros, (wv + 1) % NT, lane);
+  bf16x8 qf[KS], dof[KS];
+  {
+    bf16x8 of[KS];  // this wave's 16 query rows of O, Q, dO straight from global
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      of[ks] = gfrag(ob, (size_t)E, 16 * wv, ks, S, lane);
+      dof[ks] = gfrag(dob, (size_t)E, 16 * wv, ks, S, lane);
+      qf[ks] = gfrag(qb, ld, 16 * wv, ks, S, lane);
+    }
+    for (int i = tid; i < RP; i += 64 * NT) ll[i] = (i < S) ? lb[i] : 0.f;
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += vg_bf2f(dof[ks][j]) * vg_bf2f(of[ks][j]);
+    }
+    const float delta = group_sum(dpart);
+    if (g == 0) dl[16 * wv + li] = delta;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- phase A: S^T orientation (lane = query) -> dQ ----------------------
+  {
+    const int q = 16 * wv + li;
+    const float delta = dl[q];
+    const float lse_q = ll[q];
+    f32x4 ds[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x4 st = zero, dpt = zero;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st = score_mfma<FP8>(lfrag_row<HE>(s0, 16 * kt, ks, lane), qf[ks], st);
+        dpt = vg_mfma(lfrag_row<HE>(s1, 16 * kt, ks, lane), dof[ks], dpt);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * g + r;
+        const float p = (key < S && q < S) ? __expf(st[r] * scale - lse_q) : 0.f;
+        ds[kt][r] = p * (dpt[r] - delta) * scale;
+      }
+    }
+    bf16x8 dsf[KP];
+#pragma unroll
+    for (int u = 0; u < KP; ++u) dsf[u] = pack_pair(ds[2 * u], (2 * u + 1 < NT) ? ds[(2 * u + 1 < NT) ? 2 * u + 1 : 0] : zero);
+    bf16* rowq = dqb + (size_t)(q < S ? q : 0) * ld;
+#pragma unroll
+    for (int pp = 0; pp < DT / 2; ++pp) {  // two head-dim tiles (32 columns = one 16-byte store per lane) at a time: registers
+      f32x4 dq[2] = {zero, zero};
+#pragma unroll
+      for (int u = 0; u < KP; ++u) {
+        dq[0] = vg_mfma(lfrag_tr<HE>(s0, u, 32 * pp, lane), dsf[u], dq[0]);
+        dq[1] = vg_mfma(lfrag_tr<HE>(s0, u, 32 * pp + 16, lane), dsf[u], dq[1]);
+      }
+      store_tiles<2>(rowq + 32 * pp, dq, 1.0f, g, q < S);
+    }
+  }
+  // this wave's key tile for phase B, before Q and dO take the images over
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = lfrag_row<HE>(s0, 16 * wv, ks, lane);
+    vf[ks] = lfrag_row<HE>(s1, 16 * wv, ks, lane);
+  }
+  __syncthreads();  // (waits for the LDS reads above: every wave is done with K and V)
+  dma_head<HE, NT>(s0, qb, ld, S, RP, zeros, wv, lane);
+  dma_head<HE, NT>(s1, dob, (size_t)E, S, RP, zeros, (wv + 1) % NT, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---------------- phase B: S orientation (lane = key) -> dK, dV ---------------------
+  {
+    const int key = 16 * wv + li;
+    f32x4 pr[NT], ds[NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 s = zero, dp = zero;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = score_mfma<FP8>(lfrag_row<HE>(s0, 16 * qt, ks, lane), kf[ks], s);
+        dp = vg_mfma(lfrag_row<HE>(s1, 16 * qt, ks, lane), vf[ks], dp);
+      }
+      const f32x4 lq4 = *(const f32x4*)(ll + 16 * qt + 4 * g);
+      const f32x4 dl4 = *(const f32x4*)(dl + 16 * qt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * qt + 4 * g + r;
+        const float p = ((q < S) && (key < S)) ? __expf(s[r] * scale - lq4[r]) : 0.f;
+        pr[qt][r] = p;
+        ds[qt][r] = p * (dp[r] - dl4[r]) * scale;
+      }
+    }
+    bf16x8 pf[KP], dsf[KP];
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      const int hi = (2 * u + 1 < NT) ? 2 * u + 1 : 0;
+      pf[u] = pack_pair(pr[2 * u], (2 * u + 1 < NT) ? pr[hi] : zero);
+      dsf[u] = pack_pair(ds[2 * u], (2 * u + 1 < NT) ? ds[hi] : zero);
+    }
+    bf16* rowp = dqb + (size_t)(key < S ? key : 0) * ld;
+#pragma unroll
+    for (int pp = 0; pp < DT / 2; ++pp) {
+      f32x4 dv[2] = {zero, zero}, dk[2] = {zero, zero};
+#pragma unroll
+      for (int u = 0; u < KP; ++u) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          dv[t] = vg_mfma(lfrag_tr<HE>(s1, u, 32 * pp + 16 * t, lane), pf[u], dv[t]);
+          dk[t] = vg_mfma(lfrag_tr<HE>(s0, u, 32 * pp + 16 * t, lane), dsf[u], dk[t]);
+        }
+      }
+      store_tiles<2>(rowp + E + 32 * pp, dk, 1.0f, g, key < S);
+      store_tiles<2>(rowp + 2 * E + 32 * pp, dv, 1.0f, g, key < S);
+    }
+  }
+}
+
 __device__ __attribute__((aligned(16))) unsigned int vg_attn_zero_page[4] = {0u, 0u, 0u, 0u};
 static const void* attn_zeros() {
   static void* zp = nullptr;  // one device per process
@@ -448,6 +603,12 @@ static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const flo
                       int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
+#ifndef VG_ATTN_BWD_4IMG  // A/B builds (make var DEFS=-DVG_ATTN_BWD_4IMG): the four-image kernel everywhere
+  if constexpr (MODE != 1 && NT == 5) {
+    hipLaunchKernelGGL((vg_attn_bwd2_kernel<HE, NT, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
+    return (int)hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
   return (int)hipGetLastError();
 }
