@@ -191,11 +191,25 @@ int vg_layernorm_bwd_bwd(const void* u, const void* dy, const void* x, const flo
 int vg_attention_bwd_bwd(const void* qkv, const void* d_out, const float* lse, const void* u_qkv, void* d_d_out,
                          void* d_qkv2, int B, int H, int S, int HE, float scale, void* stream);
 
+/* Start of a training step, two launches instead of torch's seven:
+ * vg_zero_tick: g[0, n) = 0 (discriminator.zero_grad(), src/v2/training.py:177) and step_dev[0] += 1 (the device step counter that keys
+ *   the dropout masks, AdamW's bias correction and the noise below); n % 4 == 0; step_dev may be NULL.
+ * vg_step_inputs: imgs_bf16[0, n_img) = bf16(real) (real NULL: skipped) and z[0, n_z) ~ N(0, 1) (z NULL: skipped) - the latent batch of
+ *   construct_noise (training.py:35-42 = torch.randn), counter-based on (seed, step_dev[0], index): Box-Muller of two hashed 24-bit
+ *   uniforms, |z| <= 5.77; reproducible per (seed, step), fresh on every replay of a captured graph. */
+int vg_zero_tick(float* g, long long n, int* step_dev, void* stream);
+int vg_step_inputs(const float* real, void* imgs_bf16, long long n_img, float* z, long long n_z,
+                   unsigned long long seed, const int* step_dev, void* stream);
+
 /* GAN losses on logits (src/v1/gan.py:16-20,227,238,250 for kind 0; hinge for kind 1;
  * kind 2 = the Wasserstein critic losses of src/v2/training.py:72,97).
  * role 0 D-real, 1 D-fake, 2 G.  loss_out[0] = mean loss, dlogits = d loss / d logits * grad_scale. */
 int vg_gan_loss(const float* logits, float* dlogits, float* loss_out, int n, int kind, int role,
                 float grad_scale, void* stream);
+/* the same on two consecutive segments of one logit vector in ONE launch (the fused real + fake discriminator pass):
+ * logits[0, n0) with role0 -> loss_out[0], logits[n0, n0 + n1) with role1 -> loss_out[1]; each mean is over its own segment. */
+int vg_gan_loss_pair(const float* logits, float* dlogits, float* loss_out, int n0, int role0, int n1, int role1,
+                     int kind, float grad_scale, void* stream);
 
 /* torch.optim.AdamW step over a flat fp32 buffer (src/v2/training.py:150-157), also refreshing the
  * bf16 shadow the GEMMs read.  n % 4 == 0.  grads are multiplied by gscale first.  The step number

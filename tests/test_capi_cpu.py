@@ -39,6 +39,8 @@ def test_argument_validation_without_gpu():
     assert lib.vg_attention_fwd(None, None, None, 1, 1, 1, 32, 1.0, None) == -1
     assert lib.vg_linear_fwd(None, None, None, None, None, None, None, 8, 8, 8, 0, 0.0, None) == -1
     assert lib.vg_linear_gelu_fwd(None, None, None, None, None, 8, 8, 8, None) == -1
+    assert lib.vg_gan_loss_pair(None, None, None, 4, 0, 4, 1, 0, 1.0, None) == -1
+    assert lib.vg_zero_tick(None, 4, None, None) == -1 and lib.vg_step_inputs(None, None, 0, None, 0, 1, None, None) == -1
     # full-row Linear + LayerNorm entry points (csrc/gemm_row.hip): host-side shape queries and null checks
     assert lib.vg_row_parts(33280) == 256 and lib.vg_row_parts(16640) == 256 and lib.vg_row_parts(2080) == 65 and lib.vg_row_parts(130) == 0
     assert lib.vg_row_pack_elems(384) == 384 * 384 and lib.vg_row_pack_elems(40) == -2

@@ -355,6 +355,61 @@ def test_gan_loss(kind, role):
     u.assert_close(d, x.grad, 1e-5, "dlogits")
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_gan_loss_pair_is_two_single_calls(kind):
+    """The fused real + fake pass evaluates both halves' losses in one launch: bit-equal to the two single launches."""
+    u = _u()
+    g = torch.Generator().manual_seed(kind)
+    n0, n1 = 256, 256
+    x = u.dev(torch.randn(n0 + n1, generator=g) * 2)
+    d1, d2 = torch.zeros_like(x), torch.zeros_like(x)
+    l1, l2 = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    u.call("vg_gan_loss", u.ptr(x), u.ptr(d1), u.ptr(l1), n0, kind, 0, 1.0, u.stream())
+    u.call("vg_gan_loss", C.c_void_p(x.data_ptr() + 4 * n0), C.c_void_p(d1.data_ptr() + 4 * n0), C.c_void_p(l1.data_ptr() + 4), n1, kind, 1, 1.0, u.stream())
+    u.call("vg_gan_loss_pair", u.ptr(x), u.ptr(d2), u.ptr(l2), n0, 0, n1, 1, kind, 1.0, u.stream())
+    u.sync()
+    assert torch.equal(d1, d2) and torch.equal(l1, l2)
+
+
+def test_step_begin_kernels():
+    """vg_zero_tick: zero_grad + device step counter in one launch; vg_step_inputs: bf16 cast of the real batch (torch's rounding) and the
+    latent batch ~ N(0, 1), counter-based on (seed, step): reproducible, fresh per step and per seed, moments of a normal sample."""
+    u = _u()
+    g = torch.full((4096 + 4,), 3.0, device="cuda")
+    step = torch.tensor([7], dtype=torch.int32, device="cuda")
+    u.call("vg_zero_tick", u.ptr(g), 4096, u.ptr(step), u.stream())
+    u.sync()
+    assert bool((g[:4096] == 0).all()) and bool((g[4096:] == 3.0).all()) and int(step) == 8
+    real = torch.randn(8, 3, 32, 32, device="cuda")
+    imgs = torch.zeros(8, 3, 32, 32, dtype=u.BF, device="cuda")
+    n = 256 * 1024
+    z = [torch.zeros(n + 2, device="cuda") for _ in range(4)]
+    for i, (seed, st) in enumerate(((5, 8), (5, 8), (5, 9), (6, 8))):
+        step.fill_(st)
+        u.call("vg_step_inputs", u.ptr(real), u.ptr(imgs), real.numel(), u.ptr(z[i]), n, seed, u.ptr(step), u.stream())
+    u.sync()
+    assert torch.equal(imgs, real.to(u.BF))
+    assert torch.equal(z[0], z[1]) and not torch.equal(z[0], z[2]) and not torch.equal(z[0], z[3])
+    for t in z:
+        assert bool((t[n:] == 0).all())           # nothing written past n_z
+    x = z[0][:n].double().cpu()
+    m, v = float(x.mean()), float(x.var())
+    sk, ku = float(((x - m) ** 3).mean() / v ** 1.5), float(((x - m) ** 4).mean() / v ** 2)
+    assert abs(m) < 4 / n ** 0.5 and abs(v - 1) < 0.01 and abs(sk) < 0.02 and abs(ku - 3) < 0.04, (m, v, sk, ku)
+    assert float(x.abs().max()) <= 5.78
+    # neighbours (the cos / sin of one pair, consecutive pairs) and the two steps are uncorrelated
+    for a, b in ((x[:-1], x[1:]), (x[:-2], x[2:]), (x, z[2][:n].double().cpu()), (x, z[3][:n].double().cpu())):
+        assert abs(float((a * b).mean())) < 5 / n ** 0.5
+    # tail mass like a normal's: P(|z| > 3) = 2.70e-3
+    assert abs(float((x.abs() > 3).double().mean()) - 2.70e-3) < 4e-4
+    # noise only / cast only
+    z2 = torch.zeros(n, device="cuda")
+    step.fill_(8)
+    u.call("vg_step_inputs", None, None, 0, u.ptr(z2), n, 5, u.ptr(step), u.stream())
+    u.sync()
+    assert torch.equal(z2, z[0][:n])
+
+
 def test_adamw_matches_torch():
     u = _u()
     n = 4096 + 64

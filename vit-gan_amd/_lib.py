@@ -99,7 +99,10 @@ _SIGNATURES = {
     "vg_layernorm_bwd_bwd_parts": (c_int, [c_int]),
     "vg_layernorm_bwd_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "vg_attention_bwd_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_zero_tick": (c_int, [P, c_ll, P, P]),
+    "vg_step_inputs": (c_int, [P, P, c_ll, P, c_ll, C.c_ulonglong, P, P]),
     "vg_gan_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
+    "vg_gan_loss_pair": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_adamw_step": (c_int, [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "vg_diversity_loss": (c_int, [P, P, P, P, c_int, c_int, c_float, P]),
     "vg_grad_clip": (c_int, [P, c_ll, c_float, c_float, P, P]),

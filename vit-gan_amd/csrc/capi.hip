@@ -228,6 +228,20 @@ extern "C" int vg_gan_loss(const float* logits, float* dlogits, float* loss_out,
   if (!logits || !dlogits || !loss_out || n < 1) return -1;
   return vg_gan_loss_launch(logits, dlogits, loss_out, n, kind, role, grad_scale, (hipStream_t)stream);
 }
+extern "C" int vg_zero_tick(float* g, long long n, int* step_dev, void* stream) {
+  if (!g) return -1;
+  return vg_zero_tick_launch(g, n, step_dev, (hipStream_t)stream);
+}
+extern "C" int vg_step_inputs(const float* real, void* imgs_bf16, long long n_img, float* z, long long n_z, unsigned long long seed,
+                              const int* step_dev, void* stream) {
+  if ((!real && !z) || (real && !imgs_bf16)) return -1;
+  return vg_step_inputs_launch(real, (bf16*)imgs_bf16, n_img, z, n_z, seed, step_dev, (hipStream_t)stream);
+}
+extern "C" int vg_gan_loss_pair(const float* logits, float* dlogits, float* loss_out, int n0, int role0, int n1, int role1, int kind,
+                                float grad_scale, void* stream) {
+  if (!logits || !dlogits || !loss_out) return -1;
+  return vg_gan_loss_pair_launch(logits, dlogits, loss_out, n0, role0, n1, role1, kind, grad_scale, (hipStream_t)stream);
+}
 extern "C" int vg_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, const int* step_dev, float gscale,
                              void* stream) {

@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void vg_take_rows_kernel(const bf16* __restric
   const int b = (int)(r / n_take), j = (int)(r - (long long)b * n_take);
   *(u32x4*)(out + (size_t)r * E + 8 * c) = *(const u32x4*)(in + ((size_t)b * S + first + j) * E + 8 * c);
 }
-// g[(b*S + 0), :] = src[b, :], every other row of g = 0
+// g[(b*S + 0), :] = src[b, :], every other row of g = 0;  gm (nullable): g times the dropout mask of the [B*S, E] buffer
 __global__ __launch_bounds__(256) void vg_scatter_cls_kernel(const bf16* __restrict__ src, bf16* __restrict__ g, int B, int S,
-                                                             int E) {
+                                                             int E, bf16* __restrict__ gm, unsigned dthr, unsigned dkey0, float dscale,
+                                                             const unsigned* __restrict__ dstep) {
   const int cpr = E / 8;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)B * S * cpr) return;
@@ -91,6 +92,22 @@ __global__ __launch_bounds__(256) void vg_scatter_cls_kernel(const bf16* __restr
   u32x4 v = {0u, 0u, 0u, 0u};
   if (s == 0) v = *(const u32x4*)(src + (size_t)b * E + 8 * c);
   *(u32x4*)(g + (size_t)r * E + 8 * c) = v;
+  if (gm) {
+    if (s == 0) {  // same index and arithmetic as vg_dropout_apply_kernel over the whole buffer
+      const unsigned dkey = vg_drop_key(dkey0, dstep);
+      const long long i4 = (r * E + 8 * c) >> 2;
+      const bf16x8 x = __builtin_bit_cast(bf16x8, v);
+      bf16x8 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned wd = vg_drop_word(dkey, (unsigned)(i4 + h));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * h + j] = vg_f2bf(vg_bf2f(x[4 * h + j]) * vg_drop_factor(wd, j, dthr, dscale));
+      }
+      v = __builtin_bit_cast(u32x4, o);
+    }
+    *(u32x4*)(gm + (size_t)r * E + 8 * c) = v;
+  }
 }
 // out[s, e] = sum_b g[(b*S + s), e]   (fp32).  A workgroup owns 64 consecutive columns of one token row (a whole
 // 128-B line per batch item) x 32 batch lanes: 16-byte loads, 4 independent loads in flight per thread, and a
@@ -189,13 +206,112 @@ __global__ __launch_bounds__(256) void vg_head_bwd_w2_kernel(const float* __rest
   if (lane == 0) { if (e < E) dW2[(size_t)k * E + e] += a; else db2[k] += a; }
 }
 
+// The three of them in one launch (the head is 512 rows: three launches cost more than the work), fully parallel over the rows:
+// workgroup (x, y) owns 64 columns e and 32 rows b (4 waves x 8 rows, all loads in flight at once); dz as above, and per workgroup
+// ONE partial row  part[y][ k*E + e ] = sum_b dlog[b,k] t[b,e] | part[y][ Kc*E + e ] = sum_b dz[b,e] (of the ROUNDED dz, the tensor
+// the fc1 weight gradient reads) | part[y][ (Kc+1)*E + k ] = sum_b dlog[b,k]  - folded over y into dW2 / db1 / db2 by the caller's
+// deferred fold (vg_colsum_f32_multi_kernel), fixed order.  part == nullptr: dz only.
+#define VG_HEAD_KMAX 16
+#define VG_HEAD_ROWS 32
+__global__ __launch_bounds__(256) void vg_head_bwd_all_kernel(const float* __restrict__ dlog, const float* __restrict__ W2,
+                                                              const bf16* __restrict__ t, bf16* __restrict__ dz, float* __restrict__ part,
+                                                              int B, int E, int Kc) {
+  __shared__ float red[4][VG_HEAD_KMAX + 1][64];
+  __shared__ float red2[4][VG_HEAD_KMAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool eok = e < E;
+  const int b0 = blockIdx.y * VG_HEAD_ROWS + wv * 8;
+  float tv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) tv[u] = (eok && b0 + u < B) ? vg_bf2f(t[(size_t)(b0 + u) * E + e]) : 0.f;
+  float w2[VG_HEAD_KMAX], aw[VG_HEAD_KMAX], a2[VG_HEAD_KMAX];
+#pragma unroll
+  for (int k = 0; k < VG_HEAD_KMAX; ++k) { w2[k] = (k < Kc && eok) ? W2[(size_t)k * E + e] : 0.f; aw[k] = 0.f; a2[k] = 0.f; }
+  float cs = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int b = b0 + u;
+    if (b < B) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < VG_HEAD_KMAX; ++k) {
+        if (k < Kc) {
+          const float d = dlog[b * Kc + k];
+          a += d * w2[k];
+          aw[k] += d * tv[u];
+          a2[k] += d;
+        }
+      }
+      const bf16 o = vg_f2bf(a * (1.f - tv[u] * tv[u]));
+      if (eok) dz[(size_t)b * E + e] = o;
+      cs += vg_bf2f(o);
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int k = 0; k < VG_HEAD_KMAX; ++k) red[wv][k][lane] = aw[k];
+  red[wv][VG_HEAD_KMAX][lane] = cs;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < VG_HEAD_KMAX; ++k) red2[wv][k] = a2[k];  // every lane of a wave holds the same a2[k]
+  __syncthreads();
+  float* row = part + (size_t)blockIdx.y * ((size_t)(Kc + 1) * E + Kc);
+  if (wv == 0 && eok) {
+    for (int k = 0; k < Kc; ++k) row[(size_t)k * E + e] = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+    row[(size_t)Kc * E + e] = (red[0][VG_HEAD_KMAX][lane] + red[1][VG_HEAD_KMAX][lane]) + (red[2][VG_HEAD_KMAX][lane] + red[3][VG_HEAD_KMAX][lane]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < Kc)
+    row[(size_t)(Kc + 1) * E + threadIdx.x] = (red2[0][threadIdx.x] + red2[1][threadIdx.x]) + (red2[2][threadIdx.x] + red2[3][threadIdx.x]);
+}
+
+// ---- start of a training step --------------------------------------------------------------------------------------------
+// g[0, n) = 0 (zero_grad of the discriminator) and the device step counter += 1, in one launch: nothing in THIS kernel reads the
+// counter, every later kernel of the step (dropout keys, AdamW's bias correction, the latent noise below) sees the new value.
+__global__ __launch_bounds__(256) void vg_zero_tick_kernel(float* __restrict__ g, long long n, int* __restrict__ step) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 == 0 && step) step[0] += 1;
+  if (i4 < n) *(f32x4*)(g + i4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ uint32_t vg_mix32(uint32_t x) {  // "lowbias32" integer finaliser: every input bit reaches every output bit
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+// The step's inputs in one launch: imgs[0, n_img) = bf16(real) (the GEMM operand type) and, when z != nullptr, the latent batch
+// z[0, n_z) ~ N(0, 1) (construct_noise of src/v2/training.py:35-42 is torch.randn): counter-based - element pair j of step s under
+// seed k is Box-Muller of two 24-bit uniforms hashed from (k, s, j) - so a replayed hipGraph draws fresh noise every step, a resumed
+// run continues the sequence, and no generator state lives on the device.  |z| <= 5.77 (u1 >= 2^-24).
+__global__ __launch_bounds__(256) void vg_step_inputs_kernel(const float* __restrict__ real, bf16* __restrict__ imgs, long long n_img,
+                                                             float* __restrict__ z, long long n_z, uint32_t seed_lo, uint32_t seed_hi,
+                                                             const int* __restrict__ step) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i4 = t * 4;
+  if (real && i4 < n_img) {
+    const f32x4 v = *(const f32x4*)(real + i4);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = vg_f2bf(v[j]);
+    *(bf16x4*)(imgs + i4) = o;
+  }
+  if (z && 2 * t < n_z) {
+    const uint32_t key = vg_mix32(seed_lo ^ vg_mix32((uint32_t)step[0] * 0x9E3779B1u + seed_hi));
+    const uint32_t a = vg_mix32(vg_mix32((uint32_t)(2 * t) + key) ^ seed_hi), b = vg_mix32(vg_mix32((uint32_t)(2 * t + 1) + key) ^ seed_hi);
+    const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-8f;  // (0, 1]
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;         // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    z[2 * t] = r * cs;
+    if (2 * t + 1 < n_z) z[2 * t + 1] = r * sn;
+  }
+}
+
 // ---- GAN losses on logits [n] ------------------------------------------------------------------
 // kind: 0 = non-saturating BCE-with-logits (v1 gan.py:16-20 semantics), 1 = hinge.
 // role: 0 = D on real (target 1), 1 = D on fake (target 0), 2 = G (target 1 / -mean).
 // loss_out[0] = mean loss; dlog[i] = d(mean loss)/d logit[i] * grad_scale.
-__global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restrict__ logit, float* __restrict__ dlog,
-                                                          float* __restrict__ loss_out, int n, int kind, int role,
-                                                          float grad_scale) {
+__device__ __forceinline__ void vg_gan_loss_body(const float* __restrict__ logit, float* __restrict__ dlog, float* __restrict__ loss_out, int n,
+                                                 int kind, int role, float grad_scale) {
   __shared__ float red[4];
   float acc = 0.f;
   const float inv = 1.0f / (float)n;
@@ -220,6 +336,18 @@ __global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+}
+__global__ __launch_bounds__(256) void vg_gan_loss_kernel(const float* __restrict__ logit, float* __restrict__ dlog,
+                                                          float* __restrict__ loss_out, int n, int kind, int role,
+                                                          float grad_scale) {
+  vg_gan_loss_body(logit, dlog, loss_out, n, kind, role, grad_scale);
+}
+// Two segments of one logit vector (the fused real + fake discriminator pass): workgroup i takes segment i.
+__global__ __launch_bounds__(256) void vg_gan_loss_pair_kernel(const float* __restrict__ logit, float* __restrict__ dlog,
+                                                               float* __restrict__ loss_out, int n0, int role0, int n1, int role1, int kind,
+                                                               float grad_scale) {
+  if (blockIdx.x == 0) vg_gan_loss_body(logit, dlog, loss_out, n0, kind, role0, grad_scale);
+  else vg_gan_loss_body(logit + n0, dlog + n0, loss_out + 1, n1, kind, role1, grad_scale);
 }
 
 // ---- torch.nn.utils.clip_grad_norm_ over a flat gradient buffer (src/v2/training.py:78,104) -------------------------
@@ -366,6 +494,17 @@ __global__ __launch_bounds__(256) void vg_slab_reduce_kernel(const float* __rest
   for (int s = 0; s < nslab; ++s) a += *(const f32x4*)(slab + (size_t)s * stride + i4);
   *(f32x4*)(dst + i4) = a;
 }
+__global__ __launch_bounds__(256) void vg_slab_reduce2_kernel(const float* __restrict__ slab0, const float* __restrict__ slab1, long long stride,
+                                                              int nslab, float* __restrict__ dst0, float* __restrict__ dst1, long long n,
+                                                              int accumulate) {
+  const float* slab = blockIdx.y ? slab1 : slab0;
+  float* dst = blockIdx.y ? dst1 : dst0;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  f32x4 a = accumulate ? *(const f32x4*)(dst + i4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslab; ++s) a += *(const f32x4*)(slab + (size_t)s * stride + i4);
+  *(f32x4*)(dst + i4) = a;
+}
 // SIREN output-layer gradient: dz = dy * w0 * cos(w0 * z)   (z fp32 pre-activation)
 __global__ __launch_bounds__(256) void vg_sin_grad_kernel(const bf16* __restrict__ dy, const float* __restrict__ z,
                                                           bf16* __restrict__ dz, long long n, float w0) {
@@ -485,8 +624,11 @@ int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int 
   hipLaunchKernelGGL(vg_take_rows_kernel, dim3(nblk((long long)B * n_take * (E / 8))), dim3(256), 0, st, in, out, B, S, first, n_take, E);
   return (int)hipGetLastError();
 }
-int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st) {
-  hipLaunchKernelGGL(vg_scatter_cls_kernel, dim3(nblk((long long)B * S * (E / 8))), dim3(256), 0, st, src, g, B, S, E);
+int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st, bf16* gm, unsigned dthr, unsigned dkey, float dscale,
+                          const unsigned* dstep) {
+  if (E & 7) return -3;
+  hipLaunchKernelGGL(vg_scatter_cls_kernel, dim3(nblk((long long)B * S * (E / 8))), dim3(256), 0, st, src, g, B, S, E, (dthr ? gm : nullptr), dthr, dkey,
+                     dscale, dstep);
   return (int)hipGetLastError();
 }
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st) {
@@ -502,11 +644,44 @@ int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* l
   hipLaunchKernelGGL(vg_head_fc2_kernel, dim3(nblk((long long)B * Kc, 4)), dim3(256), 0, st, t, W2, b2, logits, B, E, Kc);
   return (int)hipGetLastError();
 }
+int vg_head_bwd_parts(int B) { return (B + VG_HEAD_ROWS - 1) / VG_HEAD_ROWS; }
+int vg_head_bwd_part_width(int E, int Kc) { return (Kc + 1) * E + Kc; }
+// Kc <= 16: ONE launch; with `part` ([vg_head_bwd_parts(B)][vg_head_bwd_part_width(E, Kc)] floats) the gradients of W2, b1 and b2 are
+// left as partial rows for the caller's deferred fold and 1 is returned.  Otherwise (or part == nullptr with want_wgrad): the
+// separate kernels accumulate dW2 / db2 directly (db1 is then the caller's column sum) and 0 is returned.  < 0: -hipError.
 int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* dz, float* dW2, float* db2, int B, int E, int Kc,
-                       int want_wgrad, hipStream_t st) {
+                       int want_wgrad, hipStream_t st, float* part) {
+  if (Kc <= VG_HEAD_KMAX && (!want_wgrad || part)) {
+    hipLaunchKernelGGL(vg_head_bwd_all_kernel, dim3((E + 63) / 64, vg_head_bwd_parts(B)), dim3(256), 0, st, dlog, W2, t, dz,
+                       want_wgrad ? part : nullptr, B, E, Kc);
+    const int rc = (int)hipGetLastError();
+    return rc ? -rc : (want_wgrad ? 1 : 0);
+  }
   hipLaunchKernelGGL(vg_head_bwd_dz_kernel, dim3(nblk((long long)B * E)), dim3(256), 0, st, dlog, W2, t, dz, B, E, Kc);
   if (want_wgrad)
     hipLaunchKernelGGL(vg_head_bwd_w2_kernel, dim3(nblk((long long)Kc * (E + 1), 4)), dim3(256), 0, st, dlog, t, dW2, db2, B, E, Kc);
+  const int rc = (int)hipGetLastError();
+  return rc ? -rc : 0;
+}
+int vg_zero_tick_launch(float* g, long long n, int* step, hipStream_t st) {
+  if (n < 4 || (n & 3)) return -3;
+  hipLaunchKernelGGL(vg_zero_tick_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, g, n, step);
+  return (int)hipGetLastError();
+}
+int vg_step_inputs_launch(const float* real, bf16* imgs, long long n_img, float* z, long long n_z, unsigned long long seed, const int* step,
+                          hipStream_t st) {
+  if ((real && (n_img & 3)) || (z && !step)) return -3;
+  long long thr = real ? n_img / 4 : 0;
+  if (z && (n_z + 1) / 2 > thr) thr = (n_z + 1) / 2;
+  if (thr < 1) return -2;
+  hipLaunchKernelGGL(vg_step_inputs_kernel, dim3(nblk(thr)), dim3(256), 0, st, real, imgs, real ? n_img : 0, z, z ? n_z : 0, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), step);
+  return (int)hipGetLastError();
+}
+int vg_gan_loss_pair_launch(const float* logit, float* dlog, float* loss_out, int n0, int role0, int n1, int role1, int kind, float grad_scale,
+                            hipStream_t st) {
+  if (kind < 0 || kind > 2 || role0 < 0 || role0 > 2 || role1 < 0 || role1 > 2 || n0 < 1 || n1 < 1) return -2;
+  hipLaunchKernelGGL(vg_gan_loss_pair_kernel, dim3(2), dim3(256), 0, st, logit, dlog, loss_out, n0, role0, n1, role1, kind, grad_scale);
   return (int)hipGetLastError();
 }
 int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
@@ -530,6 +705,12 @@ int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_
 int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st) {
   if (n & 3) return -3;
   hipLaunchKernelGGL(vg_slab_reduce_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, slab, stride, nslab, dst, n, accumulate);
+  return (int)hipGetLastError();
+}
+int vg_slab_reduce2_launch(const float* slab0, const float* slab1, long long stride, int nslab, float* dst0, float* dst1, long long n, int accumulate,
+                           hipStream_t st) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(vg_slab_reduce2_kernel, dim3(nblk(n / 4), 2), dim3(256), 0, st, slab0, slab1, stride, nslab, dst0, dst1, n, accumulate);
   return (int)hipGetLastError();
 }
 int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st) {

@@ -54,7 +54,7 @@ extern "C" int vg_vit_layout(const VgVitDims* d, VgVitLayout* o) {
   if (HE != 32 && HE != 64 && HE != 96) return -3;
   if (NP + 1 > 80) return -3;
   // depth: the backward queues 3 deferred folds per block and uses one event pair per block (+1 for the join)
-  if (3 * d->L > VG_MAX_FOLD_JOBS || d->L >= VG_CTX_EVENTS - 1) return -3;
+  if (3 * d->L + 2 > VG_MAX_FOLD_JOBS || d->L >= VG_CTX_EVENTS - 1) return -3;  // (+ 2: classifier head, final LayerNorm)
   long long p = 0;
   o->conv_w = p; p = al64(p + E * K);
   o->conv_b = p; p = al64(p + E);
@@ -94,7 +94,7 @@ extern "C" int vg_gen_layout(const VgGenDims* d, VgGenLayout* o) {
   const int HE = d->E / d->H;
   if (HE != 32 && HE != 64 && HE != 96) return -3;
   if (d->patch < 0) return -3;
-  if (2 * d->L + 1 > VG_MAX_FOLD_JOBS) return -3;  // the backward queues 2L+1 deferred folds
+  if (2 * d->L + 3 > VG_MAX_FOLD_JOBS) return -3;  // the backward queues 2L+1 deferred SLN folds + the two SIREN bias gradients
   if (d->patch > 0) {  // tokens on the patch grid: T and CW are determined by the image geometry
     if (d->C < 1 || d->IH < d->patch || d->IH % d->patch) return -3;
     const int gh = d->IH / d->patch;
@@ -223,7 +223,7 @@ struct VitWs {
   float* lnpart;  // [2L] LayerNorm-backward partial-sum blocks, folded by one launch at the end of a backward call
   float* bslab;   // [L][VIT_SPLIT_CAP][3E + rE + E] bias-gradient rows written by the weight-gradient GEMM, one per K slice
   bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
-  float *part, *part_cs, *tok_sum, *slab;
+  float *part, *part_cs, *hpart, *tok_sum, *slab;
   bf16* wpack;  // E = 384: stage images of Wo | W2 | Wqkv^T | W1^T per block for the full-row GEMMs (gemm_row.hip)
 };
 // The full-row GEMMs (LayerNorm in the epilogue) take the block Linears whose output is the embedding when E = 384 and the
@@ -264,6 +264,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   w.dzh = c.take<bf16>(B * E); w.dhcls = c.take<bf16>(B * E); w.dxcls = c.take<bf16>(B * E);
   w.part = c.take<float>((long long)vg_ln_bwd_nparts((int)M) * 3 * E);
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)M) * 3 * E);
+  w.hpart = c.take<float>(d.Kc <= 16 ? (long long)vg_head_bwd_parts((int)B) * vg_head_bwd_part_width((int)E, d.Kc) : 0);  // classifier head: partial gradient rows
   w.tok_sum = c.take<float>(S * E);
   long long slab = VIT_SPLIT_CAP * lay.layer_weights;
   if (EMB_SPLIT_CAP * E * Kp > slab) slab = EMB_SPLIT_CAP * E * Kp;
@@ -381,8 +382,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
-  VG_TRY(vg_take_rows_launch(w.X + (size_t)d.L * ME, w.xcls, B, S, 0, 1, E, st));
-  VG_TRY(vg_ln_fwd_launch(w.xcls, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  VG_TRY(vg_ln_fwd_launch(w.X + (size_t)d.L * ME, (long long)S * E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
   VG_TRY(lin_fwd(w.hcls, E, Pb + lay.hw1, P + lay.hb1, w.th, B, E, VG_ACT_TANH, 0.f, nullptr, nullptr, nullptr, st));
   VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
   return 0;
@@ -423,26 +423,30 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   VgCtx* ctx = (VgCtx*)net->ctx;
   hipStream_t sd = ctx ? ctx->side : st;  // stream of the weight-gradient side work
   const int top = d.L - 1;
+  VgFoldJobs folds; folds.n = 0;  // partial-sum folds queued by this call: one launch at its end
   if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
-  VG_TRY(vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr,
-                            want_wgrad ? G + lay.hb2 : nullptr, B, E, d.Kc, want_wgrad, st));
+  // dz, and the gradients of fc2 and of fc1's bias as partial rows for the fold at the end of this call: one launch
+  const int head1 = vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr, want_wgrad ? G + lay.hb2 : nullptr,
+                                       B, E, d.Kc, want_wgrad, st, (want_wgrad && d.Kc <= 16) ? w.hpart : nullptr);
+  if (head1 < 0) return -head1;
   if (want_wgrad) {
-    VG_TRY(vg_colsum_bf16_launch(w.dzh, E, B, E, w.part_cs, G + lay.hb1, 1, st));
+    if (head1) VG_TRY(vg_fold_push(folds, w.hpart, vg_head_bwd_parts(B), vg_head_bwd_part_width(E, d.Kc), G + lay.hw2, d.Kc * E, G + lay.hb1, E,
+                                   G + lay.hb2, d.Kc, nullptr, 0));
+    else VG_TRY(vg_colsum_bf16_launch(w.dzh, E, B, E, w.part_cs, G + lay.hb1, 1, st));
     VgGemmProb p = wg(w.dzh, E, w.hcls, E, B, w.slab, (long long)E * E, 1);
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
   }
   VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
-  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.xcls, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st));
-  if (want_wgrad)  // (the final LayerNorm's own partial count: B rows, standalone kernel)
-    VG_TRY(vg_colsum_f32_launch(w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0, 1, st));
-  VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st));
-  if (drop) VG_TRY(vg_dropout_apply_launch(w.set[top & 1].gin, w.set[top & 1].gm2, (long long)M * E, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step, st));
+  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)d.L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
+  if (want_wgrad)  // (the final LayerNorm's own partial count: B rows, standalone kernel; w.part is nobody else's)
+    VG_TRY(vg_fold_push(folds, w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0));
+  // dL/dX[L]: the CLS rows, zero elsewhere - and its masked copy for the last block's MLP dropout, in the same launch
+  VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st, drop ? w.set[top & 1].gm2 : nullptr, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step));
   }
 
   int last_side = -1;  // highest-index side event recorded by this call (for the join)
-  VgFoldJobs folds; folds.n = 0;
   const size_t part_sz = (size_t)lnparts * 3 * E;
   // Weight gradients (single-stream schedule): the blocks of this call are taken in PAIRS - the eight problems of two blocks
   // as ONE grouped split-K launch with half the K slices (same number of workgroups: 42 tiles x 6 instead of 21 x 12), which
@@ -485,11 +489,16 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       if (lb == top) { q[3].colsum = bs + 3 * E + rE; q[3].colsum_split_stride = BW; }
     }
     VG_TRY(vg_gemm_launch(pr, 4 * nb, VG_TN, sd));
+    if (nb == 2) {  // both blocks' K slices in one launch
+      const long long lo0 = lay.layer0 + (long long)la * lay.layer_stride, lo1 = lo0 - lay.layer_stride;
+      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, pr[0].splits, G + lo0, G + lo1,
+                                    lay.layer_weights, 1, sd));
+    }
     for (int j = 0; j < nb; ++j) {
       const int lb = la - j;
       const long long lob = lay.layer0 + (long long)lb * lay.layer_stride;
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
-      VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, pr[4 * j].splits, G + lob, lay.layer_weights, 1, sd));
+      if (nb == 1) VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lob, lay.layer_weights, 1, sd));
       VG_TRY(vg_fold_push(folds, bs, pr[4 * j].splits, (int)BW, G + lob + lay.bqkv, 3 * E, G + lob + lay.b1, rE, (lb == top) ? G + lob + lay.b2 : nullptr, E,
                           nullptr, 0));
     }
@@ -606,7 +615,7 @@ struct GenWs {
   float *lse, *mean1, *rstd1, *mean2, *rstd2, *meanf, *rstdf, *zf1, *zf2;
   bf16 *g[3], *gm[2], *dz2, *dz1, *ds, *dcat, *dqkv, *dwb;
   bf16 *y2, *dy2;  // patch-grid variant only: token rows [R, CW] before the un-patchify / after the patchify of d_img
-  float *dw_acc, *part, *part_cs, *emb_sum, *slab;
+  float *dw_acc, *part, *part_cs, *part_cs2, *emb_sum, *slab;
   bf16* wpack;  // E = 384: stage images of Wo | Wm | Wqkv^T | Wm^T per block, then s1_w^T, for the full-row GEMMs (gemm_row.hip)
 };
 // generator rows R = B*T: the full-row kernels (SLN in the epilogue) take the Linears whose output is the embedding when E = 384
@@ -645,6 +654,7 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.dw_acc = c.take<float>(R * E);
   w.part = c.take<float>((2 * L + 1) * (long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));  // one block per SLN backward
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
+  w.part_cs2 = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * d.CW);
   w.emb_sum = c.take<float>(T * E);
   long long slab = GEN_SPLIT_CAP * lay.layer_weights;
   if (GEN_SPLIT_CAP * (long long)d.O * E > slab) slab = GEN_SPLIT_CAP * (long long)d.O * E;
@@ -814,7 +824,9 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     d_rows = w.dy2;
   }
   VG_TRY(vg_sin_grad_launch(d_rows, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
-  VG_TRY(vg_colsum_bf16_launch(w.dz2, d.CW, R, d.CW, w.part_cs, G + lay.s2_b, 1, st));
+  // bias gradients of the two SIREN layers: partial column sums now, folded with the SLN partials at the end of this call
+  VG_TRY(vg_colsum_bf16_part_launch(w.dz2, d.CW, R, d.CW, w.part_cs2, st));
+  VG_TRY(vg_fold_push(folds, w.part_cs2, vg_colsum_bf16_nparts(R), d.CW, G + lay.s2_b, d.CW, nullptr, 0, nullptr, 0, nullptr, 0));
   {
     const int splits = pick_splits(tiles128(d.CW, d.O), R, GEN_SPLIT_CAP);
     VgGemmProb p = wg(w.dz2, d.CW, w.y1, d.O, R, w.slab, (long long)d.CW * d.O, splits);
@@ -822,7 +834,8 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.CW * d.O, p.splits, G + lay.s2_w, (long long)d.CW * d.O, 1, st));
   }
   VG_TRY(lin_dgrad(w.dz2, Pb + lay.s2_w, w.dz1, R, d.CW, d.O, VG_ACT_MUL_COS, nullptr, w.zf1, d.omega0, st));
-  VG_TRY(vg_colsum_bf16_launch(w.dz1, d.O, R, d.O, w.part_cs, G + lay.s1_b, 1, st));
+  VG_TRY(vg_colsum_bf16_part_launch(w.dz1, d.O, R, d.O, w.part_cs, st));
+  VG_TRY(vg_fold_push(folds, w.part_cs, vg_colsum_bf16_nparts(R), d.O, G + lay.s1_b, d.O, nullptr, 0, nullptr, 0, nullptr, 0));
   {
     const int splits = pick_splits(tiles128(d.O, E), R, GEN_SPLIT_CAP);
     VgGemmProb p = wg(w.dz1, d.O, w.sf, E, R, w.slab, (long long)d.O * E, splits);

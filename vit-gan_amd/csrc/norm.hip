@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
     const int row = row0 + rg;
     const bool ok = row < R;
     const int rr = ok ? row : 0;
-    const int xrow = x_bcast_rows > 0 ? rr % x_bcast_rows : rr;
+    // x_bcast_rows > 0: x has that many rows, broadcast over the batch; < 0: row r of the problem is row -x_bcast_rows * r of x
+    const int xrow = x_bcast_rows > 0 ? rr % x_bcast_rows : (x_bcast_rows < 0 ? rr * -x_bcast_rows : rr);
     const float mu = mean[rr], rs = rstd[rr];
     float xh[NV][CH], gg[NV][CH];
     float c1 = 0.f, c2 = 0.f;
@@ -371,9 +372,10 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 int vg_ln_bwd_nparts(int R) { const int n = (R + 15) / 16; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
-                     float dscale, const unsigned* dstep, hipStream_t st) {
-  if ((E & 127) || E > 1024 || R < 1) return -3;
-#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, LN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, 0, mean, rstd, gamma, \
+                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step) {
+  if ((E & 127) || E > 1024 || R < 1 || x_row_step < 1) return -3;
+  const int xb = x_row_step > 1 ? -x_row_step : 0;  // row r of the problem reads row x_row_step * r of x (the CLS rows of [B, S, E])
+#define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, LN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, xb, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
                      (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep)
   NV_SWITCH(E, LN_BWD)

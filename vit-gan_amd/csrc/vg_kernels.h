@@ -15,7 +15,7 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 int vg_ln_bwd_nparts(int R);
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
-                     float dscale, const unsigned* dstep, hipStream_t st);
+                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step = 1);
 int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
                       const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
@@ -38,18 +38,33 @@ int vg_fill_cls_launch(bf16* x, const float* cls, int B, int S, int E, unsigned 
 int vg_dropout_apply_launch(const bf16* x, bf16* y, long long n, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep,
                             hipStream_t st);
 int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int n_take, int E, hipStream_t st);
-int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st);
+// gm (nullable): the same rows times the dropout mask of site key dkey over the [B*S, E] buffer (what vg_dropout_apply would make of g)
+int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st, bf16* gm = nullptr, unsigned dthr = 0, unsigned dkey = 0,
+                          float dscale = 1.f, const unsigned* dstep = nullptr);
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st);
 int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st);
 int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* logits, int B, int E, int Kc, hipStream_t st);
+// one launch (returns 1: dW2 / db1 / db2 left as partial rows in `part` for a deferred fold) or the separate kernels (returns 0); < 0 error
+int vg_head_bwd_parts(int B);
+int vg_head_bwd_part_width(int E, int Kc);
 int vg_head_bwd_launch(const float* dlog, const float* W2, const bf16* t, bf16* dz, float* dW2, float* db2, int B, int E, int Kc,
-                       int want_wgrad, hipStream_t st);
+                       int want_wgrad, hipStream_t st, float* part = nullptr);
+// start of a step: zero_grad + step counter; input cast + latent noise (elementwise.hip)
+int vg_zero_tick_launch(float* g, long long n, int* step, hipStream_t st);
+int vg_step_inputs_launch(const float* real, bf16* imgs, long long n_img, float* z, long long n_z, unsigned long long seed, const int* step,
+                          hipStream_t st);
+// two segments of one logit vector in one launch: [0, n0) with role0 -> loss_out[0], [n0, n0 + n1) with role1 -> loss_out[1]
+int vg_gan_loss_pair_launch(const float* logit, float* dlog, float* loss_out, int n0, int role0, int n1, int role1, int kind, float grad_scale,
+                            hipStream_t st);
 int vg_gan_loss_launch(const float* logit, float* dlog, float* loss_out, int n, int kind, int role, float grad_scale,
                        hipStream_t st);
 int vg_adamw_launch(float* p, const float* g, float* m, float* v, bf16* shadow, long long n, float lr, float b1, float b2,
                     float eps, float wd, int step, const int* step_dev, float gscale, hipStream_t st);
 int vg_cast_f32_bf16_launch(const float* src, bf16* dst, long long n, hipStream_t st);
 int vg_slab_reduce_launch(const float* slab, long long stride, int nslab, float* dst, long long n, int accumulate, hipStream_t st);
+// two folds of the same shape in one launch (the two blocks of a paired weight-gradient launch)
+int vg_slab_reduce2_launch(const float* slab0, const float* slab1, long long stride, int nslab, float* dst0, float* dst1, long long n, int accumulate,
+                           hipStream_t st);
 int vg_sin_grad_launch(const bf16* dy, const float* z, bf16* dz, long long n, float w0, hipStream_t st);
 
 // dropout key of (seed, site): splitmix64 folded to 32 bits (the engine's site numbering: include/vitgan_hip.h, vg_dropout_apply)

@@ -52,6 +52,7 @@ class GradSync:
         capture of the step with its RCCL collectives is tested on a one-GPU box."""
         self.group = group
         self.world = world_size(group)
+        self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
         self.active = self.world > 1 or (bool(single_rank) and dist.is_available() and dist.is_initialized())
         self.cuda = device is not None and device.type == "cuda"
         self.overlap = bool(overlap) and self.cuda and self.active

@@ -112,6 +112,8 @@ class GanEngine:
         self.pg = process_group
         self.sync = GradSync(process_group, self.dev, overlap=True, single_rank=exchange_single_rank)
         self.world = self.sync.world
+        # latent noise drawn on the device (vg_step_inputs): one stream per (seed, rank)
+        self._noise_seed = (self.seed * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (self.sync.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         d, g = vit._dims, generator._dims
         if g.T * g.CW != d.C * d.IH * d.IH:
             raise ValueError("generator output does not match the discriminator's image shape")
@@ -167,7 +169,6 @@ class GanEngine:
             backend = dist.get_backend(process_group)
             if backend != "nccl":
                 self._graph_fallback(f"process-group backend '{backend}' cannot be captured in a hipGraph (only nccl = RCCL can)")
-        self._static_real = None
 
     def _graph_fallback(self, reason: str) -> None:
         self._use_graph = False
@@ -262,7 +263,7 @@ class GanEngine:
         _lib.check(L.vg_gan_loss(C.c_void_p(self.logits.data_ptr() + off), C.c_void_p(self.dlogits.data_ptr() + off),
                                  C.c_void_p(self.losses.data_ptr() + 4 * slot), n * self.Kc, self.kind, role, 1.0, st), "vg_gan_loss")
 
-    def _enqueue_two_stream(self, real: torch.Tensor) -> None:
+    def _enqueue_two_stream(self) -> None:
         """The step as two concurrent chains (see ``two_stream``).  Everything is enqueued from this thread; the second chain
         forks from and joins the current stream through events, so the whole step is still one capturable graph."""
         L, B = _lib.lib(), self.B
@@ -275,11 +276,7 @@ class GanEngine:
         off_img = lambda t, n: C.c_void_p(t.data_ptr() + n * img_bytes)  # noqa: E731
         off_log = lambda t, n: C.c_void_p(t.data_ptr() + n * Kc4)       # noqa: E731
         fake_ptr = off_img(self.imgs, B)
-        self.step_t += 1
-        self.imgs[:B].copy_(real)
-        if not self.external_noise:
-            self.z.normal_()
-        fd.grad.zero_()
+        _lib.check(L.vg_zero_tick(_p(fd.grad), fd.total, _p(self.step_t), st0), "vg_zero_tick")
         self.grad2.zero_()
         d_in = self.imgs
         s1.wait_stream(s0)
@@ -328,21 +325,38 @@ class GanEngine:
         _lib.check(L.vg_gen_backward(C.byref(ng), B, _p(self.ws_g), _p(self.dfake), st0), "vg_gen_backward")
         self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st0, self.clip_g, 1)
 
+    def _inputs(self, real: torch.Tensor) -> None:
+        """The step's inputs, ONE launch in front of the step proper (and outside its hipGraph, so it reads the caller's tensor
+        directly - no staging copy): imgs[:B] = bf16(real), and unless the caller supplies it, the latent batch z ~ N(0, 1)
+        (construct_noise(), training.py:35-42 / gan.py:231-232), counter-based on (seed, rank, steps done so far)."""
+        B = self.B
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        direct = real.dtype == torch.float32 and real.is_contiguous() and real[0].numel() == self.imgs[0].numel() and real.numel() % 4 == 0
+        if not direct:
+            self.imgs[:B].copy_(real)
+        want_z = not self.external_noise
+        if direct or want_z:
+            _lib.check(_lib.lib().vg_step_inputs(_p(real) if direct else None, _p(self.imgs), real.numel() if direct else 0,
+                                                 _p(self.z) if want_z else None, self.z.numel() if want_z else 0, self._noise_seed,
+                                                 _p(self.step_t), st), "vg_step_inputs")
+
     def _enqueue(self, real: torch.Tensor) -> None:
         """Enqueue one full step on the current stream (no host sync)."""
+        self._inputs(real)
+        self._enqueue_body()
+
+    def _enqueue_body(self) -> None:
+        """Everything of a step behind its inputs (``_inputs``): what the hipGraph captures."""
         if self.two_stream:
-            return self._enqueue_two_stream(real)
+            return self._enqueue_two_stream()
         L, B = _lib.lib(), self.B
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         (nd, nd_b, nd_c), ng = self._nets()
         fd, fg = self.vit._flat, self.gen._flat
         img_bytes = self.imgs[0].numel() * 2
         fake_ptr = C.c_void_p(self.imgs.data_ptr() + B * img_bytes)
-        self.step_t += 1
-        self.imgs[:B].copy_(real)  # fp32 -> bf16 (the GEMM operand type)
-        if not self.external_noise:
-            self.z.normal_()       # construct_noise(), training.py:35-42 / gan.py:231-232
-        fd.grad.zero_()            # gan.discriminator.zero_grad(), training.py:177
+        # gan.discriminator.zero_grad() (training.py:177) and the device step counter += 1, one launch
+        _lib.check(L.vg_zero_tick(_p(fd.grad), fd.total, _p(self.step_t), st), "vg_zero_tick")
         _lib.check(L.vg_gen_forward(C.byref(ng), B, _p(self.z), _p(self.ws_g), fake_ptr, st), "vg_gen_forward")
         d_in = self.imgs
         if self.inst_sigma > 0.0:  # noisy_real / noisy_fake of training.py:83-90 (the clean fake stays in self.imgs for pass C)
@@ -359,8 +373,9 @@ class GanEngine:
             self.gp_loss.copy_(pen.detach().reshape(1))
         if self.fuse:
             _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(d_in), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")
-            self._loss(0, B, 0, 0, st)
-            self._loss(B, B, 1, 1, st)
+            # D(real) -> slot 0, D(fake) -> slot 1: both halves of the fused pass in one launch
+            _lib.check(_lib.lib().vg_gan_loss_pair(_p(self.logits), _p(self.dlogits), _p(self.losses), B * self.Kc, 0, B * self.Kc, 1, self.kind,
+                                                   1.0, st), "vg_gan_loss_pair")
             self._d_backward(nd, 2 * B, _p(self.dlogits), 1, None, st)
         else:
             for half, role in ((0, 0), (1, 1)):
@@ -422,22 +437,22 @@ class GanEngine:
             self._enqueue(real)
             return self.losses
         if self._graph is None:
-            self._static_real = real.clone()
             # Warm-up on a side stream (allocator, lazily loaded code objects), then capture.  The warm-up is a real step:
             # the training state is saved before it and restored after it, so N calls of step() are N steps in graph
             # mode exactly as in eager mode (tests compare the two bit for bit).
             saved = [t.clone() for t in self._state_tensors()]
             s = torch.cuda.Stream()
+            self._inputs(real)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self._enqueue(self._static_real)
+                self._enqueue_body()
             torch.cuda.current_stream().wait_stream(s)
             for t, keep in zip(self._state_tensors(), saved):
                 t.copy_(keep)
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
-                    self._enqueue(self._static_real)
+                    self._enqueue_body()
             except Exception as exc:  # only reachable with collectives in the step: otherwise it is all our own enqueue-only calls
                 if not self.sync.active:
                     raise
@@ -449,6 +464,6 @@ class GanEngine:
                 self._enqueue(real)
                 return self.losses
             self._graph = graph
-        self._static_real.copy_(real)
+        self._inputs(real)
         self._graph.replay()
         return self.losses
