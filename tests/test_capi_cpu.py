@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu():
 
 
 def test_unsupported_depths_are_rejected_not_overflowed():
-    """the backward queues 3 folds per ViT block (2L+1 for the generator) into a 40-entry host array and uses
+    """the backward queues 3 folds per ViT block (2L+1 for the generator) into a 42-entry host array (+ 2 for the head and the final LayerNorm, + 2 for the SIREN biases) and uses
     one event pair per block; depths beyond that used to write past the array.  The layouts now refuse them."""
     lib = _lib.lib()
     ok = _lib.VgVitDims(3, 32, 4, 128, 4, 13, 2, 1)

@@ -1,6 +1,6 @@
 // Deferred partial-sum folds (see vg_colsum_f32_multi_kernel in norm.hip).
 #pragma once
-#define VG_MAX_FOLD_JOBS 40
+#define VG_MAX_FOLD_JOBS 42
 struct VgFoldJob {
   const float* part; int rows, width;   // partial rows [rows][width]
   float* dst[4]; int n[4];              // up to 4 consecutive column segments, accumulated (+=) into dst (nullptr = skip)
