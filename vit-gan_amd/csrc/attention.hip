@@ -160,16 +160,32 @@ __device__ __forceinline__ void row_sqnorms(const unsigned char* img, float* out
 // v1 attention score (src/v1/attention.py:66-67): the Euclidean distance |q - k| from q.k and the squared norms
 __device__ __forceinline__ float l2_dist(float qk, float qn, float kn) { return sqrtf(fmaxf(qn + kn - 2.f * qk, 0.f)); }
 
+// workgroup -> (image, head).  The heads of one image read interleaved 2 HE-byte slices of the same rows of qkv / o / d_o
+// (HE = 96: 192-byte segments, 1.5 cache lines - neighbouring heads share a line), and consecutive workgroup ids go round-robin
+// over the 8 XCDs, each with its own L2: the heads of an image therefore sit on ONE XCD, as consecutive workgroups of it
+// (id = 8 i + x: image 8 (i / H) + x, head i % H), so a shared line is fetched from HBM once.
+__device__ __forceinline__ bool attn_block(int B, int H, int& b, int& h) {
+#ifdef VG_ATTN_LINEAR_MAP  // A/B builds: the plain mapping
+  b = blockIdx.x / H; h = blockIdx.x - b * H;
+#else
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  b = (i / H) * 8 + x; h = i % H;
+#endif
+  return b < B;
+}
+static inline int attn_grid(int B, int H) { return ((B + 7) / 8) * 8 * H; }
+
 template <int HE, int NT, bool L2, bool FP8>
 __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                              float* __restrict__ lse, int S, int H, float scale,
+                                                              float* __restrict__ lse, int B, int S, int H, float scale,
                                                               const void* __restrict__ zeros) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32, RK = 16 * NT;
   __shared__ __attribute__((aligned(16))) unsigned char sm[(RK + RP) * HE * 2 + (L2 ? RK * 4 : 0)];
   unsigned char* kl = sm;                 // K, rows [0, 16 NT): row-form fragments
   unsigned char* vl = sm + RK * HE * 2;   // V, rows [0, 32 KP): transposed fragments
   float* kn = (float*)(sm + (RK + RP) * HE * 2);  // L2 scores: |k|^2 per key
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
   const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6;  // wave qt owns query rows 16*qt .. 16*qt+15
   const int g = lane >> 4, li = lane & 15;
   const int E = H * HE;
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(64 * NT) void vg_attn_fwd_kernel(const bf16* __rest
 template <int HE, int NT, bool L2, bool FP8>
 __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                         bf16* __restrict__ dqkv, int B, int S, int H, float scale,
                                                          const void* __restrict__ zeros) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
   constexpr int IMG = RP * HE * 2;
@@ -273,7 +289,8 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
   float* ll = dl + RP;                 // lse[q]
   float* qn_l = ll + RP;               // L2 scores: |q|^2 per query, |k|^2 per key
   float* kn_l = qn_l + RP;
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
   const int g = lane >> 4, li = lane & 15;
   const int E = H * HE;
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(64 * NT, 2) void vg_attn_bwd_kernel(const bf16* __r
 template <int HE, int NT, bool FP8>
 __global__ __launch_bounds__(64 * NT, VG_ATTN_BWD2_WPE) void vg_attn_bwd2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                   const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                                  bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                                  bf16* __restrict__ dqkv, int B, int S, int H, float scale,
                                                                   const void* __restrict__ zeros) {
   constexpr int KS = HE / 32, DT = HE / 16, KP = (NT + 1) / 2, RP = KP * 32;
   constexpr int IMG = RP * HE * 2;
@@ -451,7 +468,8 @@ __global__ __launch_bounds__(64 * NT, VG_ATTN_BWD2_WPE) void vg_attn_bwd2_kernel
   unsigned char* s1 = sm + IMG;  // V, then dO
   float* dl = (float*)(sm + 2 * IMG);  // delta[q] = sum_d dO*O
   float* ll = dl + RP;                 // lse[q]
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;  // wave wv owns query tile wv (phase A) / key tile wv (phase B)
   const int g = lane >> 4, li = lane & 15;
   const int E = H * HE;
@@ -595,7 +613,7 @@ template <int HE, int NT, int MODE>  // MODE: 0 dot-product bf16, 1 L2-distance 
 static int launch_fwd(const bf16* qkv, bf16* o, float* lse, int B, int H, int S, float scale, hipStream_t st) {
   const void* z = attn_zeros();
   if (!z) return -5;
-  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, lse, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_fwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(attn_grid(B, H)), dim3(64 * NT), 0, st, qkv, o, lse, B, S, H, scale, z);
   return (int)hipGetLastError();
 }
 template <int HE, int NT, int MODE>
@@ -605,11 +623,11 @@ static int launch_bwd(const bf16* qkv, const bf16* o, const bf16* d_o, const flo
   if (!z) return -5;
 #ifndef VG_ATTN_BWD_4IMG  // A/B builds (make var DEFS=-DVG_ATTN_BWD_4IMG): the four-image kernel everywhere
   if constexpr (MODE != 1 && NT == 5) {
-    hipLaunchKernelGGL((vg_attn_bwd2_kernel<HE, NT, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
+    hipLaunchKernelGGL((vg_attn_bwd2_kernel<HE, NT, MODE == 2>), dim3(attn_grid(B, H)), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, B, S, H, scale, z);
     return (int)hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(B * H), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, S, H, scale, z);
+  hipLaunchKernelGGL((vg_attn_bwd_kernel<HE, NT, MODE == 1, MODE == 2>), dim3(attn_grid(B, H)), dim3(64 * NT), 0, st, qkv, o, d_o, lse, dqkv, B, S, H, scale, z);
   return (int)hipGetLastError();
 }
 
