@@ -160,7 +160,7 @@ def step_roofline(torch, B, reps=30):
         ("vg_gemm_tn384_kernel<6>: QKV weight gradient (one of the four problems of a block's grouped launch; + its slab fold)", [1152, 384, M],
          lambda: chk(L.vg_linear_wgrad(p(x1152), p(x384), p(dw), p(slab), slab.numel(), M, 1152, 384, WG_SPLITS, 1, st), "vg_linear_wgrad"),
          2.0 * M * 1152 * 384, 2 * (M * 1152 + M * 384) + 4 * WG_SPLITS * 1152 * 384, "tn qkv wgrad"),
-        ("vg_attn_bwd_kernel<96,5>: fused attention backward, one workgroup per (image, head)", [2 * B, H, S, HE],
+        ("vg_attn_bwd2_kernel<96,5>: fused attention backward, one workgroup per (image, head), two LDS images", [2 * B, H, S, HE],
          lambda: chk(L.vg_attention_bwd(p(x1152), p(x384), p(res), p(lse), p(o1152), 2 * B, H, S, HE, 1.0 / HE ** 0.5, st), "vg_attention_bwd"),
          10.0 * 2 * B * H * S * S * HE, 2 * (M * 1152 * 2 + M * 384 * 2) + 4 * 2 * B * H * S, None),
         ("vg_gemm_wr_kernel<0,1,2>: fc1 + GELU, gelu' for the backward as one byte per element", [M, 768, 384],
