@@ -602,6 +602,225 @@ __global__ __launch_bounds__(64 * NT, VG_ATTN_BWD2_WPE) void vg_attn_bwd2_kernel
   }
 }
 
+// ---- the backward OF the attention backward (gradient penalty, src/v2/utils.py:124-144) on the MFMA pipe -------------------
+// Forward: P = softmax(s Q K^T), O = P V.  Backward: dV = P^T dO ; dP = dO V^T ; delta_i = sum_j P_ij dP_ij ; dS = P (dP - delta) ;
+// dQ = s dS K ; dK = s dS^T Q.  Given (uQ, uK, uV) = dL/d(dQ, dK, dV):
+//   G = s (uQ K^T + Q uK^T) ; gam_i = sum_j G_ij P_ij ; H = P (G - gam)                       [dL/d dP]
+//   Pi = dO uV^T + G (dP - delta) - gam dP ; pi_i = sum_j P_ij Pi_ij ; Sg = P (Pi - pi)       [dL/d S]
+//   d(dO) = P uV + H V ;  d(Q) = s (dS uK + Sg K) ;  d(K) = s (dS^T uQ + Sg^T Q) ;  d(V) = H^T dO.
+// Same two-orientation scheme as the first-order backward: phase A (lane = query; K, V, uK, uV as LDS images, this wave's 16 rows of
+// Q, dO, uQ as fragments straight from global) computes the five S x S products of a query tile against every key tile in MFMA
+// accumulators, the three row sums (delta, gam, pi; left in LDS for phase B) and the query-side outputs d(dO), d(Q); phase B
+// (lane = key; Q, dO, uQ staged into the same images, this wave's rows of K, V, uK, uV kept as fragments) recomputes the products in
+// the other orientation and yields d(K), d(V).  The S x S matrices never leave registers (round 2's kernel kept four of them as fp32
+// in LDS and ran plain FMA loops: 1.2 ms per launch); they enter the output products as bf16, like P and dS in the first-order
+// backward.  One workgroup per (image, head), five waves, 74 KB of LDS.
+template <int HE>
+__global__ __launch_bounds__(320, 2) void vg_attn_bwd_bwd2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                                  const float* __restrict__ lse, const bf16* __restrict__ uqkv,
+                                                                  bf16* __restrict__ d_do, bf16* __restrict__ d_qkv, int B, int S, int H,
+                                                                  float scale, const void* __restrict__ zeros) {
+  constexpr int NT = 5, KS = HE / 32, DT = HE / 16, KP = 3, RP = 96;
+  constexpr int IMG = RP * HE * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4 * IMG + 4 * RP * 4];
+  unsigned char* i0 = sm;            // K,  then Q
+  unsigned char* i1 = sm + IMG;      // V,  then dO
+  unsigned char* i2 = sm + 2 * IMG;  // uK, then uQ
+  unsigned char* i3 = sm + 3 * IMG;  // uV
+  float* dl = (float*)(sm + 4 * IMG);  // delta[q]
+  float* gm = dl + RP;                 // gam[q]
+  float* pl = gm + RP;                 // pi[q]
+  float* ll = pl + RP;                 // lse[q]
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int E = H * HE;
+  const size_t ld = 3 * (size_t)E;
+  const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
+  const bf16* kb = qb + E;
+  const bf16* vb = qb + 2 * E;
+  const bf16* uqb = uqkv + (size_t)b * S * ld + h * HE;
+  const bf16* ukb = uqb + E;
+  const bf16* uvb = uqb + 2 * E;
+  const bf16* dob = d_o + (size_t)b * S * E + h * HE;
+  const float* lb = lse + ((size_t)b * H + h) * S;
+  bf16* ddob = d_do + (size_t)b * S * E + h * HE;
+  bf16* dqb = d_qkv + (size_t)b * S * ld + h * HE;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  dma_head<HE, NT>(i0, kb, ld, S, RP, zeros, wv, lane);
+  dma_head<HE, NT>(i1, vb, ld, S, RP, zeros, (wv + 1) % NT, lane);
+  dma_head<HE, NT>(i2, ukb, ld, S, RP, zeros, (wv + 2) % NT, lane);
+  dma_head<HE, NT>(i3, uvb, ld, S, RP, zeros, (wv + 3) % NT, lane);
+  bf16x8 qf[KS], dof[KS], uqf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = gfrag(qb, ld, 16 * wv, ks, S, lane);
+    dof[ks] = gfrag(dob, (size_t)E, 16 * wv, ks, S, lane);
+    uqf[ks] = gfrag(uqb, ld, 16 * wv, ks, S, lane);
+  }
+  for (int i = tid; i < RP; i += 64 * NT) ll[i] = (i < S) ? lb[i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- phase A: lane = query li of tile wv; keys 16 kt + 4 g + r -------------------------------------------
+  {
+    const int q = 16 * wv + li;
+    const float lse_q = ll[q];
+    f32x4 Pm[NT], Dm[NT], Gm[NT], Tm[NT];
+    float delta = 0.f, gam = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x4 st = zero, dpt = zero, gt = zero, tt = zero;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kr = lfrag_row<HE>(i0, 16 * kt, ks, lane);
+        st = vg_mfma(kr, qf[ks], st);
+        gt = vg_mfma(kr, uqf[ks], gt);
+        gt = vg_mfma(lfrag_row<HE>(i2, 16 * kt, ks, lane), qf[ks], gt);
+        dpt = vg_mfma(lfrag_row<HE>(i1, 16 * kt, ks, lane), dof[ks], dpt);
+        tt = vg_mfma(lfrag_row<HE>(i3, 16 * kt, ks, lane), dof[ks], tt);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * g + r;
+        const float p = (key < S && q < S) ? __expf(st[r] * scale - lse_q) : 0.f;
+        const float gv = gt[r] * scale;
+        Pm[kt][r] = p; Dm[kt][r] = dpt[r]; Gm[kt][r] = gv; Tm[kt][r] = tt[r];
+        delta += p * dpt[r];
+        gam += p * gv;
+      }
+    }
+    delta = group_sum(delta);
+    gam = group_sum(gam);
+    float pis = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = Dm[kt][r] - delta;
+        const float pie = Tm[kt][r] + Gm[kt][r] * a - gam * Dm[kt][r];
+        Tm[kt][r] = pie;                 // Pi
+        Dm[kt][r] = a;                   // dP - delta
+        pis += Pm[kt][r] * pie;
+      }
+    pis = group_sum(pis);
+    if (g == 0) { dl[q] = delta; gm[q] = gam; pl[q] = pis; }
+    // H = P (G - gam) -> Gm ;  dS = P (dP - delta) -> Dm ;  Sg = P (Pi - pi) -> Tm
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = Pm[kt][r];
+        Gm[kt][r] = p * (Gm[kt][r] - gam);
+        Dm[kt][r] = p * Dm[kt][r];
+        Tm[kt][r] = p * (Tm[kt][r] - pis);
+      }
+    bf16x8 pf[KP], hf[KP], dsf[KP], sgf[KP];
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      const bool two = 2 * u + 1 < NT;
+      const int hi = two ? 2 * u + 1 : 0;
+      pf[u] = pack_pair(Pm[2 * u], two ? Pm[hi] : zero);
+      hf[u] = pack_pair(Gm[2 * u], two ? Gm[hi] : zero);
+      dsf[u] = pack_pair(Dm[2 * u], two ? Dm[hi] : zero);
+      sgf[u] = pack_pair(Tm[2 * u], two ? Tm[hi] : zero);
+    }
+    bf16* rowo = ddob + (size_t)(q < S ? q : 0) * E;
+    bf16* rowq = dqb + (size_t)(q < S ? q : 0) * ld;
+#pragma unroll
+    for (int pp = 0; pp < DT / 2; ++pp) {  // two head-dim tiles at a time (one 16-byte store per lane)
+      f32x4 o1[2] = {zero, zero}, o2[2] = {zero, zero};
+#pragma unroll
+      for (int u = 0; u < KP; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int d0 = 32 * pp + 16 * t;
+          o1[t] = vg_mfma(lfrag_tr<HE>(i3, u, d0, lane), pf[u], o1[t]);   // P uV
+          o1[t] = vg_mfma(lfrag_tr<HE>(i1, u, d0, lane), hf[u], o1[t]);   // + H V
+          o2[t] = vg_mfma(lfrag_tr<HE>(i2, u, d0, lane), dsf[u], o2[t]);  // dS uK
+          o2[t] = vg_mfma(lfrag_tr<HE>(i0, u, d0, lane), sgf[u], o2[t]);  // + Sg K
+        }
+      store_tiles<2>(rowo + 32 * pp, o1, 1.0f, g, q < S);
+      store_tiles<2>(rowq + 32 * pp, o2, scale, g, q < S);
+    }
+  }
+  // this wave's key tile for phase B, before Q, dO, uQ take the images over
+  bf16x8 kf[KS], vf[KS], ukf[KS], uvf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = lfrag_row<HE>(i0, 16 * wv, ks, lane);
+    vf[ks] = lfrag_row<HE>(i1, 16 * wv, ks, lane);
+    ukf[ks] = lfrag_row<HE>(i2, 16 * wv, ks, lane);
+    uvf[ks] = lfrag_row<HE>(i3, 16 * wv, ks, lane);
+  }
+  __syncthreads();  // every wave is done with K, V, uK, uV (and delta / gam / pi of every query are in LDS)
+  dma_head<HE, NT>(i0, qb, ld, S, RP, zeros, wv, lane);
+  dma_head<HE, NT>(i1, dob, (size_t)E, S, RP, zeros, (wv + 1) % NT, lane);
+  dma_head<HE, NT>(i2, uqb, ld, S, RP, zeros, (wv + 2) % NT, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---------------- phase B: lane = key li of tile wv; queries 16 qt + 4 g + r -------------------------------------------
+  {
+    const int key = 16 * wv + li;
+    f32x4 Hm[NT], Dm[NT], Sm[NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 st = zero, dpt = zero, gt = zero, tt = zero;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 qr = lfrag_row<HE>(i0, 16 * qt, ks, lane);
+        const bf16x8 dr = lfrag_row<HE>(i1, 16 * qt, ks, lane);
+        st = vg_mfma(qr, kf[ks], st);
+        gt = vg_mfma(qr, ukf[ks], gt);
+        gt = vg_mfma(lfrag_row<HE>(i2, 16 * qt, ks, lane), kf[ks], gt);
+        dpt = vg_mfma(dr, vf[ks], dpt);
+        tt = vg_mfma(dr, uvf[ks], tt);
+      }
+      const f32x4 lq4 = *(const f32x4*)(ll + 16 * qt + 4 * g);
+      const f32x4 dl4 = *(const f32x4*)(dl + 16 * qt + 4 * g);
+      const f32x4 gm4 = *(const f32x4*)(gm + 16 * qt + 4 * g);
+      const f32x4 pl4 = *(const f32x4*)(pl + 16 * qt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * qt + 4 * g + r;
+        const float p = ((q < S) && (key < S)) ? __expf(st[r] * scale - lq4[r]) : 0.f;
+        const float gv = gt[r] * scale, a = dpt[r] - dl4[r];
+        const float pie = tt[r] + gv * a - gm4[r] * dpt[r];
+        Hm[qt][r] = p * (gv - gm4[r]);
+        Dm[qt][r] = p * a;
+        Sm[qt][r] = p * (pie - pl4[r]);
+      }
+    }
+    bf16x8 hf[KP], dsf[KP], sgf[KP];
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      const bool two = 2 * u + 1 < NT;
+      const int hi = two ? 2 * u + 1 : 0;
+      hf[u] = pack_pair(Hm[2 * u], two ? Hm[hi] : zero);
+      dsf[u] = pack_pair(Dm[2 * u], two ? Dm[hi] : zero);
+      sgf[u] = pack_pair(Sm[2 * u], two ? Sm[hi] : zero);
+    }
+    bf16* rowp = dqb + (size_t)(key < S ? key : 0) * ld;
+#pragma unroll
+    for (int pp = 0; pp < DT / 2; ++pp) {
+      f32x4 dk[2] = {zero, zero}, dv[2] = {zero, zero};
+#pragma unroll
+      for (int u = 0; u < KP; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int d0 = 32 * pp + 16 * t;
+          dk[t] = vg_mfma(lfrag_tr<HE>(i2, u, d0, lane), dsf[u], dk[t]);  // dS^T uQ
+          dk[t] = vg_mfma(lfrag_tr<HE>(i0, u, d0, lane), sgf[u], dk[t]);  // + Sg^T Q
+          dv[t] = vg_mfma(lfrag_tr<HE>(i1, u, d0, lane), hf[u], dv[t]);   // H^T dO
+        }
+      store_tiles<2>(rowp + E + 32 * pp, dk, scale, g, key < S);
+      store_tiles<2>(rowp + 2 * E + 32 * pp, dv, 1.0f, g, key < S);
+    }
+  }
+}
+
 __device__ __attribute__((aligned(16))) unsigned int vg_attn_zero_page[4] = {0u, 0u, 0u, 0u};
 static const void* attn_zeros() {
   static void* zp = nullptr;  // one device per process
@@ -657,4 +876,16 @@ int vg_attn_fwd_launch(const bf16* qkv, bf16* o, float* lse, int B, int H, int S
 int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse, bf16* dqkv, int B, int H,
                        int S, int HE, float scale, int mode, hipStream_t st) {
   VG_ATTN_DISPATCH(launch_bwd, qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
+}
+
+// the second-order kernel above (S <= 80: padded to five 16-row tiles); -3: head dim not 32 / 64 / 96
+int vg_attn_bwd_bwd_mfma_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
+                                int S, int HE, float scale, hipStream_t st) {
+  if (S < 1 || S > 80 || B < 1 || H < 1) return -2;
+  const void* z = attn_zeros();
+  if (!z) return -5;
+#define VG_ABB2(HE_) hipLaunchKernelGGL((vg_attn_bwd_bwd2_kernel<HE_>), dim3(attn_grid(B, H)), dim3(320), 0, st, qkv, d_o, lse, uqkv, d_do, d_qkv, B, S, H, scale, z)
+  if (HE == 96) VG_ABB2(96); else if (HE == 64) VG_ABB2(64); else if (HE == 32) VG_ABB2(32); else return -3;
+#undef VG_ABB2
+  return (int)hipGetLastError();
 }

@@ -2,9 +2,12 @@
 // Wasserstein step needs (src/v2/utils.py:124-144: d/d theta of ||d D(x)/d x||).  With these every
 // backward operator of the discriminator has its own backward; the GEMM-shaped second-order terms reuse the GEMM family
 // (the backward of dX = dY W is d(dY) = ddX W^T and dW = dY^T ddX).  They serve the penalty term only - a few launches per
-// step beside the fused passes - so they are written for clarity and determinism (fp32 math, no atomics), not for the MFMA
-// roof: the attention kernel keeps a head's S x S matrices in LDS and uses plain FMA loops.
+// step beside the fused passes - so the elementwise ones are written for clarity and determinism (fp32 math, no atomics); the
+// attention double backward, which was 18 % of the penalty step as fp32 FMA loops, runs on the MFMA pipe since round 3 (attention.hip).
 #include "vg_common.h"
+// the MFMA form of the attention double backward lives with the attention kernels (attention.hip)
+int vg_attn_bwd_bwd_mfma_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
+                                int S, int HE, float scale, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------------------
 // activations: f = gelu (mode 1, exact erf) or tanh (mode 3) on a stored bf16 pre-activation h
@@ -56,74 +59,85 @@ int vg_act2_launch(const bf16* h, const bf16* dy, const bf16* u, bf16* o0, bf16*
 //   d(xh) = -r (g mean(u xh) + b u)          (explicit)           d(r) = <u, dx> / r =: c   (explicit)
 //   d(x)  = r (d(xh) - mean(d(xh)) - xh mean(d(xh) xh)) - r^2 xh c / E
 // One wave per row (E <= 1024: up to 16 elements per lane), fp32 math; d(gamma) leaves as one partial row per workgroup.
+// NE = E / 64 elements per lane, a compile-time constant: with the runtime count of the first version (16-element arrays behind
+// `if (i < NE)`) the kernel held 256 registers and 464 bytes of scratch at one wave per SIMD - 292 us per launch over 16 640 rows.
+template <int NE>
 __global__ __launch_bounds__(256) void vg_ln_bwd_bwd_kernel(const bf16* __restrict__ u, const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, bf16* __restrict__ d_dy, bf16* __restrict__ d_x,
-                                                            float* __restrict__ part, int R, int E) {
-  __shared__ float red[4][1024];
+                                                            float* __restrict__ part, int R) {
+  constexpr int E = 64 * NE;
+  __shared__ float red[4][E];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int NE = E / 64;  // elements per lane (E % 64 == 0)
-  float accg[16];
+  float accg[NE], gam[NE];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) accg[i] = 0.f;
-  const float invE = 1.0f / (float)E;
+  for (int i = 0; i < NE; ++i) { accg[i] = 0.f; gam[i] = gamma[lane + 64 * i]; }
+  constexpr float invE = 1.0f / (float)E;
   for (int row = blockIdx.x * 4 + wv; row < R; row += gridDim.x * 4) {
     const float mu = mean[row], r = rstd[row];
-    float xh[16], g[16], uu[16], dyv[16];
+    float xh[NE], g[NE], uu[NE], dyv[NE];
     float s_u = 0.f, s_ux = 0.f, s_g = 0.f, s_gx = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < NE) {
-        const int c = lane + 64 * i;
-        const size_t o = (size_t)row * E + c;
-        xh[i] = (vg_bf2f(x[o]) - mu) * r;
-        dyv[i] = vg_bf2f(dy[o]);
-        g[i] = dyv[i] * gamma[c];
-        uu[i] = vg_bf2f(u[o]);
-        s_u += uu[i]; s_ux += uu[i] * xh[i]; s_g += g[i]; s_gx += g[i] * xh[i];
-      }
+    for (int i = 0; i < NE; ++i) {
+      const size_t o = (size_t)row * E + lane + 64 * i;
+      xh[i] = (vg_bf2f(x[o]) - mu) * r;
+      dyv[i] = vg_bf2f(dy[o]);
+      uu[i] = vg_bf2f(u[o]);
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      g[i] = dyv[i] * gam[i];
+      s_u += uu[i]; s_ux += uu[i] * xh[i]; s_g += g[i]; s_gx += g[i] * xh[i];
     }
     s_u = vg_wave_sum(s_u) * invE; s_ux = vg_wave_sum(s_ux) * invE; s_g = vg_wave_sum(s_g) * invE; s_gx = vg_wave_sum(s_gx) * invE;
     // c = <u, dx> / r = sum u (g - a - xh b)
     float c = 0.f, s_d = 0.f, s_dx = 0.f;
-    float dxh[16];
+    float dxh[NE];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < NE) {
-        c += uu[i] * (g[i] - s_g - xh[i] * s_gx);
-        dxh[i] = -r * (g[i] * s_ux + s_gx * uu[i]);
-        s_d += dxh[i]; s_dx += dxh[i] * xh[i];
-      }
+    for (int i = 0; i < NE; ++i) {
+      c += uu[i] * (g[i] - s_g - xh[i] * s_gx);
+      dxh[i] = -r * (g[i] * s_ux + s_gx * uu[i]);
+      s_d += dxh[i]; s_dx += dxh[i] * xh[i];
     }
     c = vg_wave_sum(c); s_d = vg_wave_sum(s_d) * invE; s_dx = vg_wave_sum(s_dx) * invE;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < NE) {
-        const int cidx = lane + 64 * i;
-        const size_t o = (size_t)row * E + cidx;
-        const float dg = r * (uu[i] - s_u - xh[i] * s_ux);
-        d_dy[o] = vg_f2bf(dg * gamma[cidx]);
-        accg[i] += dg * dyv[i];
-        d_x[o] = vg_f2bf(r * (dxh[i] - s_d - xh[i] * s_dx) - r * r * xh[i] * c * invE);
-      }
+    for (int i = 0; i < NE; ++i) {
+      const size_t o = (size_t)row * E + lane + 64 * i;
+      const float dg = r * (uu[i] - s_u - xh[i] * s_ux);
+      d_dy[o] = vg_f2bf(dg * gam[i]);
+      accg[i] += dg * dyv[i];
+      d_x[o] = vg_f2bf(r * (dxh[i] - s_d - xh[i] * s_dx) - r * r * xh[i] * c * invE);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < NE) red[wv][lane + 64 * i] = accg[i];
+  for (int i = 0; i < NE; ++i) red[wv][lane + 64 * i] = accg[i];
   __syncthreads();
   for (int c = threadIdx.x; c < E; c += 256) part[(size_t)blockIdx.x * E + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-int vg_ln_bwd_bwd_nparts(int R) { const int n = (R + 3) / 4; return n < 256 ? n : 256; }
+// one partial row of d(gamma) per workgroup.  2048, not 256: the kernel is a chain of row reductions, latency-bound - at 256 workgroups (one wave per
+// SIMD) a launch over 16 640 rows took 292 us for 64 MB; with 8 workgroups per CU the other waves cover the chain
+int vg_ln_bwd_bwd_nparts(int R) { const int n = (R + 3) / 4; return n < 2048 ? n : 2048; }
 int vg_ln_bwd_bwd_launch(const bf16* u, const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                          bf16* d_dy, bf16* d_x, float* part, int R, int E, hipStream_t st) {
   if ((E & 63) || E > 1024 || R < 1) return -3;
-  hipLaunchKernelGGL(vg_ln_bwd_bwd_kernel, dim3(vg_ln_bwd_bwd_nparts(R)), dim3(256), 0, st, u, dy, x, mean, rstd, gamma, d_dy, d_x, part, R, E);
+#define VG_LNBB(NE_) hipLaunchKernelGGL((vg_ln_bwd_bwd_kernel<NE_>), dim3(vg_ln_bwd_bwd_nparts(R)), dim3(256), 0, st, u, dy, x, mean, rstd, gamma, d_dy, d_x, part, R)
+  switch (E / 64) {  // the embedding widths of the configurations (128 .. 1024)
+    case 2: VG_LNBB(2); break;
+    case 4: VG_LNBB(4); break;
+    case 6: VG_LNBB(6); break;
+    case 8: VG_LNBB(8); break;
+    case 12: VG_LNBB(12); break;
+    case 16: VG_LNBB(16); break;
+    default: return -3;
+  }
+#undef VG_LNBB
   return (int)hipGetLastError();
 }
 
+#ifdef VG_ABB_FMA
 // ---------------------------------------------------------------------------------------------------------------------
-// Attention backward's backward, one workgroup per (image, head).  Forward: P = softmax(s Q K^T), O = P V.  Backward:
+// Attention backward's backward, round 2's form (A/B builds only: make var SRC=second_order DEFS=-DVG_ABB_FMA; the product runs
+// vg_attn_bwd_bwd2_kernel of attention.hip, 18 x faster, same formulas).  One workgroup per (image, head).  Forward: P = softmax(s Q K^T), O = P V.  Backward:
 //   dV = P^T dO ; dP = dO V^T ; delta_i = sum_j P_ij dP_ij ; dS = P (dP - delta) ; dQ = s dS K ; dK = s dS^T Q.
 // Given (uQ, uK, uV) = dL/d(dQ, dK, dV):
 //   G = s (uQ K^T + Q uK^T) ; gam_i = sum_j G_ij P_ij ; H = P (G - gam)                       [dL/d dP]
@@ -223,9 +237,13 @@ __global__ __launch_bounds__(256) void vg_attn_bwd_bwd_kernel(const bf16* __rest
     dq[(size_t)j * ld + 2 * E + d] = vg_f2bf(o2);
   }
 }
+#endif
 int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
                            int S, int HE, float scale, hipStream_t st) {
   if (S < 1 || S > 80 || B < 1 || H < 1) return -2;
+#ifndef VG_ABB_FMA
+  return vg_attn_bwd_bwd_mfma_launch(qkv, d_o, lse, uqkv, d_do, d_qkv, B, H, S, HE, scale, st);  // attention.hip: on the MFMA pipe since round 3
+#else
   const size_t lds = (size_t)7 * S * HE * 2 + (size_t)4 * S * S * 4 + (size_t)2 * S * 4;  // 155 KB at S = 65, HE = 96
   if (lds > 160 * 1024) return -3;
 #define VG_ABB(HE_)                                                                                                           \
@@ -237,4 +255,5 @@ int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, c
   if (HE == 96) VG_ABB(96); else if (HE == 64) VG_ABB(64); else if (HE == 32) VG_ABB(32); else return -3;
 #undef VG_ABB
   return (int)hipGetLastError();
+#endif
 }

@@ -272,8 +272,11 @@ class VisionTransformer(nn.Module):
         B, Cc, IH, IW = x.shape
         P, E = emb.conv1.kernel_size[0], emb.conv1.out_channels
         gh, gw = IH // P, IW // P
-        tiles = x.reshape(B, Cc, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cc * P * P)
-        tok = ops2.linear(tiles, emb.conv1.weight.reshape(E, -1), emb.conv1.bias) + emb.pos_embedding
+        # The operators exchange bf16-VALUED tensors in the caller's dtype; with an fp32 caller every operator boundary was a pair of
+        # cast kernels over [B*S, E..4E] (8.7 ms of the 26 ms penalty step).  The pass therefore runs in bf16 from the patch tiles on:
+        # the same values, the residual adds and autograd's gradient sums round once as before; only the input gradient is cast back.
+        tiles = x.reshape(B, Cc, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cc * P * P).to(torch.bfloat16)
+        tok = ops2.linear(tiles, emb.conv1.weight.reshape(E, -1), emb.conv1.bias) + emb.pos_embedding.to(torch.bfloat16)
         h = emb.dropout(torch.cat((emb.cls_token.expand(B, 1, E).to(tok.dtype), tok), dim=1))
         for blk in self.encoder:
             a = blk.attention

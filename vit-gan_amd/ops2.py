@@ -25,6 +25,26 @@ from .ops import BF, _bf, _bias_grad, _f32, _need_cuda, _p, _st, _wgrad
 
 ACTS = {"gelu": 1, "tanh": 3}
 
+# Set (by ``input_grad_only()``) while a backward pass is run for the INPUT gradient alone - the first backward of the gradient penalty,
+# ``torch.autograd.grad(out, inputs=interpolated, create_graph=True)``: autograd calls every operator's backward on the path and throws
+# the parameter gradients away (a third of the penalty's weight-gradient GEMMs and all of its first-level bias / LayerNorm folds).
+_INPUT_GRAD_ONLY = False
+
+
+class input_grad_only:
+    """``with ops2.input_grad_only(): torch.autograd.grad(out, x, create_graph=True)`` - the operators' first-level backwards skip the
+    parameter gradients nobody asked for (they return None for them, which autograd reads as zero)."""
+
+    def __enter__(self):
+        global _INPUT_GRAD_ONLY
+        self._prev, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+        return self
+
+    def __exit__(self, *exc):
+        global _INPUT_GRAD_ONLY
+        _INPUT_GRAD_ONLY = self._prev
+        return False
+
 
 def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
@@ -102,6 +122,8 @@ class Linear2(torch.autograd.Function):
         M, N, N0, K, has_b, xshape, xdtype = ctx.dims
         dy2 = dy.reshape(M, N0)
         dx = _LinearDgrad.apply(dy2, weight)                    # differentiable
+        if _INPUT_GRAD_ONLY:
+            return dx.reshape(xshape).to(xdtype), None, None
         dyb = _pad_cols(_bf(dy2), N)
         dW = _wgrad(dyb, xb, M, N, K)[:N0]
         db = _bias_grad(dyb, M, N)[:N0] if has_b else None
@@ -125,7 +147,8 @@ class _LayerNormBwd(torch.autograd.Function):
         _lib.check(L.vg_layernorm_bwd(_p(dyb), _p(xb), _p(mean), _p(rstd), _p(g), None, _p(dx), _p(part), R, E, _st()), "vg_layernorm_bwd")
         dg = torch.empty(E, dtype=torch.float32, device=dy.device)
         db = torch.empty(E, dtype=torch.float32, device=dy.device)
-        _lib.check(L.vg_colsum_f32(_p(part), parts, 3 * E, _p(dg), E, _p(db), E, None, E, None, 0, 0, _st()), "vg_colsum_f32")
+        if not _INPUT_GRAD_ONLY:  # (else: never read - LayerNorm2.backward drops them)
+            _lib.check(L.vg_colsum_f32(_p(part), parts, 3 * E, _p(dg), E, _p(db), E, None, E, None, 0, 0, _st()), "vg_colsum_f32")
         ctx.save_for_backward(dyb, xb, g, mean, rstd)
         ctx.dims = (R, E, dy.dtype, x.dtype)
         ctx.mark_non_differentiable(dg, db)
@@ -169,6 +192,8 @@ class LayerNorm2(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         R, E = ctx.dims
         dx, dg, db = _LayerNormBwd.apply(dy.reshape(R, E), x.reshape(R, E), gamma, mean, rstd)
+        if _INPUT_GRAD_ONLY:
+            return dx.reshape(x.shape), None, None, None
         return dx.reshape(x.shape), dg, db, None
 
 

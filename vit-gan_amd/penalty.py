@@ -23,7 +23,9 @@ def gradient_penalty(discriminator, real_images: torch.Tensor, fake_images: torc
     interpolated = (epsilon * real_images.float() + (1 - epsilon) * fake_images.float()).detach().requires_grad_(True)
     vit = discriminator.vit if hasattr(discriminator, "vit") else discriminator
     out = vit.twice_differentiable_forward(interpolated)
-    (gradients,) = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones_like(out), create_graph=True,
-                                       retain_graph=True, only_inputs=True)
+    from . import ops2
+    with ops2.input_grad_only():  # this backward is for d out / d interpolated alone: no parameter gradients
+        (gradients,) = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones_like(out), create_graph=True,
+                                           retain_graph=True, only_inputs=True)
     gradient_norm = gradients.reshape(batch_size, -1).norm(2, dim=1)
     return ((gradient_norm - 1) ** 2).mean()
