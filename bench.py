@@ -303,7 +303,7 @@ def main():
     else:
         G = SirenGenerator(image_size=IMG, embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
                            dropout=0.2 if args.dropout else 0.0).to(dev).train()
-    use_graph = (True if args.graph < 0 else bool(args.graph)) and args.gp == 0.0
+    use_graph = True if args.graph < 0 else bool(args.graph)
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                     concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
                     compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp)

@@ -167,4 +167,30 @@ def test_engine_step_with_gradient_penalty():
     upd, ref_upd = D.state_dict()[k].detach().cpu() - w0[k], oracle.d[k].detach() - w0[k]
     assert float((upd - ref_upd).abs().max()) < 1.1e-3 and float(((upd - ref_upd).abs() < 1e-4).float().mean()) > 0.9
     with pytest.raises(ValueError):
-        GanEngine(D, G, batch=B, gp_weight=1.0, use_graph=True)
+        GanEngine(D, G, batch=B, gp_weight=1.0, two_stream=True)
+
+
+def test_engine_step_with_gradient_penalty_replays_as_a_graph():
+    """The penalty's autograd passes captured in the step's hipGraph: three replayed steps equal three eager steps bit for bit
+    (dropout off and epsilon fixed: the only randomness of the penalty pass), and the capture really is active."""
+    from vit_gan_amd.engine import GanEngine
+    from test_engine_gpu import _build
+    B = 8
+    g = torch.Generator().manual_seed(0)
+    reals = [(torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda() for _ in range(3)]
+    zs = [torch.randn(B, 1024, generator=g).cuda() for _ in range(3)]
+    eps = torch.rand(B, 1, 1, 1, generator=g).cuda()
+    out = []
+    for use_graph in (False, True):
+        D, G, _ = _build(B, "wasserstein")
+        eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True, use_graph=use_graph,
+                        d_dropout=0.0, g_dropout=0.0)
+        eng.gp_epsilon = eps
+        ls = [eng.step(r, z).clone() for r, z in zip(reals, zs)]
+        torch.cuda.synchronize()
+        assert eng.graph_active == use_graph and eng.graph_fallback_reason is None
+        out.append((torch.stack(ls).cpu(), D.vit._flat.flat.detach().cpu().clone(), float(eng.gp_loss)))
+        eng.close()
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] and out[0][2] > 0

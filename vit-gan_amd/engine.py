@@ -62,7 +62,9 @@ class GanEngine:
         gp_weight: weight of the WGAN-GP gradient penalty in the discriminator loss (``c.lambda_gp`` of training.py:106; the
         field is missing from the reference's Config).  The penalty runs through torch autograd over the twice-
         differentiable operator set (penalty.py) on the discriminator's real / fake inputs of this step and accumulates
-        into the same gradient buffer before the exchange and AdamW; not capturable in a hipGraph.
+        into the same gradient buffer before the exchange and AdamW.  With ``use_graph`` the autograd passes are captured with
+        the rest of the step (every operator is an enqueue-only kernel call; epsilon and the penalty pass's dropout masks come
+        from torch's graph-safe generator), so a replay costs no Python dispatch; if the capture fails the step runs eager, loudly.
         compress_mapping_grad (data parallel only, default OFF): exchange the gradient of the generator's mapping Linear - 50 MB of
         the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).  The sum is
         then formed in bf16 inside the collective (8 mantissa bits, error growing with the world size), so the default step is
@@ -97,8 +99,8 @@ class GanEngine:
         self.gp_w = float(gp_weight)
         self.gp_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.gp_epsilon: Optional[torch.Tensor] = None  # tests: a fixed epsilon [B,1,1,1] instead of torch.rand
-        if self.gp_w != 0.0 and (use_graph or two_stream):
-            raise ValueError("gp_weight: the gradient penalty runs through torch autograd and cannot be captured / forked")
+        if self.gp_w != 0.0 and two_stream:
+            raise ValueError("gp_weight: the gradient penalty runs through torch autograd on one stream and cannot be forked")
         if self.gp_w != 0.0 and bool(getattr(vit, "attention_fp8", False)):
             # the penalty path (ops2.py) differentiates the bf16 attention kernels: with fp8 operands in the trained network
             # it would penalise a slightly different function than the one being trained
@@ -453,14 +455,15 @@ class GanEngine:
             try:
                 with torch.cuda.graph(graph):
                     self._enqueue_body()
-            except Exception as exc:  # only reachable with collectives in the step: otherwise it is all our own enqueue-only calls
-                if not self.sync.active:
+            except Exception as exc:  # only reachable with collectives or the autograd-driven penalty in the step: otherwise it is all our own enqueue-only calls
+                if not self.sync.active and self.gp_w == 0.0:
                     raise
                 torch.cuda.synchronize()
                 for t, keep in zip(self._state_tensors(), saved):  # a broken capture must not have advanced the state
                     t.copy_(keep)
                 self.sync._pending.clear()
-                self._graph_fallback(f"capturing the step with its collectives failed: {type(exc).__name__}: {exc}")
+                self._graph_fallback(f"capturing the step ({'collectives' if self.sync.active else 'gradient penalty through torch autograd'}) failed: "
+                                     f"{type(exc).__name__}: {exc}")
                 self._enqueue(real)
                 return self.losses
             self._graph = graph
