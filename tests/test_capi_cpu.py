@@ -205,3 +205,55 @@ def test_oracle_is_only_reachable_from_the_allowed_places():
             for f in files:
                 if f.endswith(".py"):
                     assert oracle_imports(os.path.join(dirpath, f)) == [], f
+
+
+def test_gemm_wr_seam_wait_matches_the_compiled_store_count(tmp_path):
+    """csrc/gemm_wr.hip's seam wait `s_waitcnt vmcnt(4 + EST)` hard-codes how many vector-memory stores the epilogue of the previous
+    (always full, 8 m-tile) tile has in flight: EST = 8 per output.  If a compiler ever emitted FEWER store instructions for that
+    epilogue, the wait would stop covering the next stage's LDS-DMA pieces (rare wrong tiles).  Build-time check on the
+    ISA hipcc actually generates: in every instantiation the full tile's epilogue - the stores between the 192 MFMAs of the first
+    tile variant and the next MFMA - is exactly 8 `global_store_dwordx4` per bf16 output (+ 8 `global_store_dwordx2` for the byte codes).  (A heuristic on the
+    listing's layout, not a proof: a toolchain that moves the blocks around fails it and asks for a human look, which is the point.)"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    src = os.path.join(ROOT, "vit-gan_amd", "csrc", "gemm_wr.hip")
+    out = tmp_path / "gemm_wr.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", os.path.dirname(src),
+                    "-I", os.path.join(ROOT, "include"), src, "-o", str(out)], check=True, capture_output=True)
+    kernels, name = {}, None
+    for line in out.read_text().splitlines():
+        m = re.match(r"^(_Z\d+vg_gemm_wr_kernelILi(\d)ELi(\d)ELi(\d)E\w*):", line)
+        if m:
+            name = tuple(int(x) for x in m.groups()[1:])
+            kernels[name] = {"mfma": 0, "x4": 0, "x2": 0, "done": False}
+            continue
+        if line.startswith("\t.end_amdhsa_kernel") or line.startswith(".Lfunc_end"):
+            name = None
+        if name is None:
+            continue
+        k = kernels[name]
+        ins = line.split()[0] if line.split() else ""
+        if ins.startswith("v_mfma"):
+            if k["mfma"] == 192 and (k["x4"] or k["x2"]):
+                k["done"] = True   # first MFMA behind the full tile's epilogue: stop counting
+            k["mfma"] += 1
+        elif k["mfma"] <= 192 and not k["done"]:  # (block layout may rotate the tile loop: a store of the epilogue can sit above the MFMAs)
+            if ins == "global_store_dwordx4":
+                k["x4"] += 1
+            elif ins == "global_store_dwordx2":
+                k["x2"] += 1
+            elif ins.startswith(("global_store", "flat_store", "buffer_store", "scratch_store")):
+                raise AssertionError(f"{name}: unexpected store form {ins} in the full tile's epilogue")
+    assert len(kernels) >= 6, sorted(kernels)
+    for (wtr, act, feat), k in sorted(kernels.items()):
+        has_c2 = bool(feat & 2)
+        assert k["mfma"] >= 192, (wtr, act, feat, k)
+        # with a second output every slot has its bf16 form (dwordx4) and its byte-code form (dwordx2) behind a wave-uniform branch:
+        # one of the two executes, so 8 + 8 stores are in flight for 16 + 8 in the listing
+        want4, want2 = (16, 8) if has_c2 else (8, 0)
+        assert k["x4"] == want4, f"<{wtr},{act},{feat}>: {k['x4']} global_store_dwordx4 in the full tile's epilogue, the seam wait assumes {want4}"
+        assert k["x2"] == want2, f"<{wtr},{act},{feat}>: {k['x2']} global_store_dwordx2 (byte codes), the seam wait assumes {want2}"

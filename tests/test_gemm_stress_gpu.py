@@ -45,6 +45,40 @@ def test_forward_and_input_gradient_repeatable(M, N, K):
         assert torch.equal(outs[i], outs[0]) and torch.equal(dxs[i], dxs[0]), f"launch {i} differs bitwise from launch 0"
 
 
+@pytest.mark.parametrize("M", [1312, 16640])
+def test_gelu_and_byte_derivative_epilogues_repeatable(M):
+    """The weights-in-registers kernel's seam wait (vmcnt(4 + EST), csrc/gemm_wr.hip) counts the stores of the previous tile's
+    epilogue, and the epilogues differ per instantiation: the two the step runs beside the plain ones - fc1 + GELU with the
+    one-byte derivative as second output (<0, 1, 2>) and the fc2 input gradient times the decoded byte (<1, 8, 0>) - get the same
+    screen: many launches, other traffic in flight, every result bit-equal to the first and right against fp32."""
+    u = _u()
+    E, H = 384, 768
+    g = torch.Generator().manual_seed(M)
+    A = u.dev(u.rbf(torch.randn(M, E, generator=g)), u.BF)
+    W1 = u.dev(u.rbf(torch.randn(H, E, generator=g) / math.sqrt(E)), u.BF)
+    b1 = u.dev(torch.randn(H, generator=g) * 0.1)
+    dY = u.dev(u.rbf(torch.randn(M, E, generator=g)), u.BF)
+    W2 = u.dev(u.rbf(torch.randn(E, H, generator=g) / math.sqrt(H)), u.BF)
+    pre = A.float() @ W1.float().t() + b1
+    ref_g = torch.nn.functional.gelu(pre)
+    outs = [torch.empty(M, H, dtype=u.BF, device="cuda") for _ in range(REPS)]
+    codes = [torch.empty(M, H, dtype=torch.uint8, device="cuda") for _ in range(REPS)]
+    dxs = [torch.empty(M, H, dtype=u.BF, device="cuda") for _ in range(REPS)]
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for i in range(REPS):
+        u.call("vg_linear_gelu_fwd", u.ptr(A), u.ptr(W1), u.ptr(b1), u.ptr(outs[i]), u.ptr(codes[i]), M, H, E, u.stream())
+        if i % 3 == 0:
+            noise.add_(1)
+        u.call("vg_linear_dgrad", u.ptr(dY), u.ptr(W2), u.ptr(dxs[i]), M, E, H, 8, u.ptr(codes[i]), None, 0.0, u.stream())
+    u.sync()
+    ref_d = (dY.float() @ W2.float()) * ((codes[0].float() - 27.0) * 0.005)
+    tol_g, tol_d = 2.0 ** -7 * float(ref_g.abs().max()), 2.0 ** -7 * float(ref_d.abs().max())
+    for i in range(REPS):
+        assert float((outs[i].float() - ref_g).abs().max()) <= tol_g, f"gelu, launch {i}"
+        assert float((dxs[i].float() - ref_d).abs().max()) <= tol_d, f"input gradient x byte derivative, launch {i}"
+        assert torch.equal(outs[i], outs[0]) and torch.equal(codes[i], codes[0]) and torch.equal(dxs[i], dxs[0]), f"launch {i} differs bitwise"
+
+
 # stages per K slice: 22/22/21, 26, 52, 1, 2, 3, 4 and 5 (the ring holds four: prologue-only, one refill, steady state)
 @pytest.mark.parametrize("M,N,K,splits", [(2080, 1152, 384, 3), (4160, 768, 1536, 5), (16640, 384, 768, 10), (96, 384, 384, 3),
                                           (256, 384, 384, 4), (288, 128, 384, 3), (512, 256, 768, 4), (800, 384, 384, 5),
