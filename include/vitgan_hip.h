@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 6
+#define VG_ABI_VERSION 7
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -61,6 +61,13 @@ int vg_linear_dgrad(const void* dY, const void* W, void* dX, int M, int N, int K
 long long vg_linear_wgrad_slab_floats(int N, int K, int splits); /* host only; -2 for a bad argument */
 int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* slab_ws, long long slab_floats, int M,
                     int N, int K, int splits, int accumulate, void* stream);
+/* n <= 8 weight gradients over the same M rows as ONE grouped split-K launch and ONE fold (ABI v7; what the gradient penalty's
+ * double backward uses for a block's four Linears, src/v2/utils.py:124-144 through autograd of src/v2/modules.py:128-139,173-182):
+ * problem j's slices go to slab_ws + off[j] + s*region_floats, the regions [off[j], off[j] + N[j]*K[j]) must tile
+ * [0, region_floats) exactly (-2 otherwise: a gap would fold uninitialised memory), dst[0..region_floats) (+)= the fold. */
+int vg_linear_wgrad_group(int n, const void* const* dY, const void* const* X, const int* N, const int* K, const long long* off,
+                          int M, int splits, float* slab_ws, long long slab_floats, float* dst, long long region_floats,
+                          int accumulate, void* stream);
 
 /* nn.LayerNorm forward/backward (src/v2/modules.py:168,172,225; eps 1e-5, biased variance).
  * x,y bf16 [R,E] with row strides xs/ys (elements); mean/rstd fp32 [R]. E % 128 == 0, E <= 1024. */

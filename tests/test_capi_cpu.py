@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vitgan_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert set(_lib._SIGNATURES) <= set(names), set(_lib._SIGNATURES) - set(names)
-    assert lib.vg_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.vg_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_validation_without_gpu():
@@ -83,6 +83,13 @@ def test_wgrad_slab_validation_without_gpu():
     assert lib.vg_linear_wgrad(fake, fake, fake, fake, 8 * 384 * 384 - 1, 1024, 384, 384, 8, 0, None) == -2
     assert lib.vg_linear_wgrad(fake, fake, fake, fake, 1 << 40, 1024, 384, 384, 65, 0, None) == -2
     assert lib.vg_linear_wgrad(fake, fake, fake, None, 1 << 40, 1024, 384, 384, 2, 0, None) == -1
+    # grouped form: the problems' regions must tile the fold region exactly (no gap, no overlap), the slab must hold every slice
+    ptrs, two = (C.c_void_p * 2)(0x1000, 0x1000), (C.c_int * 2)(384, 384)
+    ok_off, gap_off, lap_off = (C.c_longlong * 2)(384 * 384, 0), (C.c_longlong * 2)(0, 384 * 384 + 8), (C.c_longlong * 2)(0, 384 * 383)
+    grp = lambda off, slab, region=2 * 384 * 384, splits=4: lib.vg_linear_wgrad_group(2, ptrs, ptrs, two, two, off, 1024, splits, fake, slab, fake, region, 1, None)  # noqa: E731
+    assert grp(gap_off, 1 << 40) == -2 and grp(lap_off, 1 << 40) == -2 and grp(ok_off, 4 * 2 * 384 * 384 - 1) == -2
+    assert grp(ok_off, 1 << 40, splits=65) == -2 and grp(ok_off, 1 << 40, region=2 * 384 * 384 + 1) == -2
+    assert lib.vg_linear_wgrad_group(9, ptrs, ptrs, two, two, ok_off, 1024, 4, fake, 1 << 40, fake, 2 * 384 * 384, 1, None) == -1
 
 
 def test_product_library_reads_no_environment():

@@ -194,3 +194,42 @@ def test_engine_step_with_gradient_penalty_replays_as_a_graph():
     assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2] and out[0][2] > 0
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_deferred_grouped_weight_gradients_equal_autograd(B):
+    """ops2.deferred_weight_grads: the block Linears' two weight-gradient contributions each, queued and sent as one grouped split-K
+    launch + one fold per block and contribution (vg_linear_wgrad_group), against the same backward through plain autograd (one
+    launch, fold and AccumulateGrad per contribution).  Same products, another K partition and summation order: fp32 round-off apart."""
+    from vit_gan_amd import ops2
+    from vit_gan_amd.penalty import gradient_penalty
+    from test_engine_gpu import _build
+    D, _, _ = _build(B, "wasserstein")
+    fl = D.vit._flat
+    g = torch.Generator().manual_seed(B)
+    real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+    fake = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+    eps = torch.rand(B, 1, 1, 1, generator=g).cuda()
+    out = []
+    for deferred in (False, True):
+        fl.attach_grads()
+        fl.grad.zero_()
+        pen = gradient_penalty(D, real, fake, epsilon=eps)
+        if deferred:
+            with ops2.deferred_weight_grads(fl.grad) as q:
+                pen.backward()
+                assert len(q.items) == 2 * 4 * len(D.vit.encoder)  # two contributions to each of a block's four weights
+        else:
+            pen.backward()
+        torch.cuda.synchronize()
+        out.append(fl.grad.detach().clone())
+    a, b = out
+    assert float(a.abs().max()) > 0
+    for name, (off, shape) in fl.slots.items():
+        n = int(torch.tensor(shape).prod())
+        ga, gb = a[off:off + n], b[off:off + n]
+        scale = float(ga.abs().max())
+        if name.endswith("weight") and ".encoder." in "." + name and ("attention" in name or "fc" in name):
+            assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, name   # regrouped fp32 sums of the same bf16 products
+        else:
+            assert torch.equal(ga, gb), name                                    # everything else took the same path

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VITGAN_HIP_LIB", os.path.join(_HERE, "libvitgan_hip.s
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
-ABI_VERSION = 6  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
+ABI_VERSION = 7  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
 
 
 class VgVitDims(C.Structure):
@@ -69,6 +69,7 @@ _SIGNATURES = {
     "vg_linear_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_float, P]),
     "vg_linear_wgrad_slab_floats": (c_ll, [c_int, c_int, c_int]),
     "vg_linear_wgrad": (c_int, [P, P, P, P, c_ll, c_int, c_int, c_int, c_int, c_int, P]),
+    "vg_linear_wgrad_group": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, c_ll, P, c_ll, c_int, P]),
     "vg_layernorm_fwd": (c_int, [P, c_ll, P, P, P, c_ll, P, P, c_int, c_int, c_float, P]),
     "vg_layernorm_bwd_parts": (c_int, [c_int]),
     "vg_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),

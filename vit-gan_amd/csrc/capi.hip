@@ -49,6 +49,37 @@ extern "C" int vg_linear_wgrad(const void* dY, const void* X, float* dW, float* 
   VG_TRY(vg_gemm_launch(&p, 1, VG_TN, (hipStream_t)stream));
   return vg_slab_reduce_launch(slab_ws, (long long)N * K, p.splits, dW, (long long)N * K, accumulate, (hipStream_t)stream);
 }
+// Several weight gradients that share their row count as ONE grouped split-K launch and ONE fold: problem j writes its K slices at
+// slab_ws + off[j] (+ s * region_floats per slice), the regions [off[j], off[j] + N[j] K[j]) must tile [0, region_floats) exactly -
+// the layout of a block's weights in the flat gradient buffer - and dst[0 .. region_floats) (+)= the folded slices.
+extern "C" int vg_linear_wgrad_group(int n, const void* const* dY, const void* const* X, const int* N, const int* K, const long long* off,
+                                     int M, int splits, float* slab_ws, long long slab_floats, float* dst, long long region_floats,
+                                     int accumulate, void* stream) {
+  if (n < 1 || n > 8 || !dY || !X || !N || !K || !off || !slab_ws || !dst) return -1;
+  if (M < 1 || splits < 1 || splits > VG_WGRAD_MAX_SPLITS || region_floats < 1) return -2;
+  if (slab_floats < (long long)splits * region_floats) return -2;
+  int order[8];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)  // insertion sort by offset
+    for (int j = i; j > 0 && off[order[j]] < off[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  long long at = 0;
+  for (int i = 0; i < n; ++i) {
+    const int j = order[i];
+    if (!dY[j] || !X[j]) return -1;
+    if (N[j] < 1 || K[j] < 1 || off[j] != at) return -2;  // a gap would fold uninitialised slab memory into dst, an overlap would race
+    at += (long long)N[j] * K[j];
+  }
+  if (at != region_floats) return -2;
+  VgGemmProb pr[8];
+  for (int j = 0; j < n; ++j) {
+    VgGemmProb p = vg_gemm_prob();
+    p.A = (const bf16*)dY[j]; p.lda = N[j]; p.B = (const bf16*)X[j]; p.ldb = K[j]; p.M = N[j]; p.N = K[j]; p.K = M;
+    p.Cf = slab_ws + off[j]; p.ldcf = K[j]; p.cf_split_stride = region_floats; p.splits = splits;
+    pr[j] = p;
+  }
+  VG_TRY(vg_gemm_launch(pr, n, VG_TN, (hipStream_t)stream));
+  return vg_slab_reduce_launch(slab_ws, region_floats, pr[0].splits, dst, region_floats, accumulate, (hipStream_t)stream);
+}
 extern "C" int vg_layernorm_fwd(const void* x, long long xs, const float* gamma, const float* beta, void* y, long long ys,
                                 float* mean, float* rstd, int R, int E, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) return -1;

@@ -370,8 +370,10 @@ class GanEngine:
             from .penalty import gradient_penalty
             fd.attach_grads()
             disc = self.vit
+            from . import ops2
             pen = gradient_penalty(disc, d_in[:B], d_in[B:], epsilon=self.gp_epsilon)
-            (self.gp_w * pen).backward()   # accumulates into the flat gradient buffer (the parameters' .grad are views of it)
+            with ops2.deferred_weight_grads(fd.grad):  # the block Linears' weight gradients: grouped per block, straight into the flat buffer
+                (self.gp_w * pen).backward()   # the rest accumulates into the same buffer through the parameters' .grad (views of it)
             self.gp_loss.copy_(pen.detach().reshape(1))
         if self.fuse:
             _lib.check(L.vg_vit_forward(C.byref(nd), 2 * B, _p(d_in), 1, _p(self.ws_d), _p(self.logits), st), "vg_vit_forward")

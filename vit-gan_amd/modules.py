@@ -278,16 +278,23 @@ class VisionTransformer(nn.Module):
         tiles = x.reshape(B, Cc, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cc * P * P).to(torch.bfloat16)
         tok = ops2.linear(tiles, emb.conv1.weight.reshape(E, -1), emb.conv1.bias) + emb.pos_embedding.to(torch.bfloat16)
         h = emb.dropout(torch.cat((emb.cls_token.expand(B, 1, E).to(tok.dtype), tok), dim=1))
-        for blk in self.encoder:
+        # where each block Linear's weight gradient lives in the flat buffer (q | k | v are contiguous there, and the four weights of a
+        # block tile one region): inside ops2.deferred_weight_grads the penalty's weight gradients then go out grouped per block
+        sl = self._flat.slots
+        for i, blk in enumerate(self.encoder):
             a = blk.attention
+            o_qkv, o_wo = sl[f"encoder.{i}.attention.queries.weight"][0], sl[f"encoder.{i}.attention.out_projection.weight"][0]
+            o_w1, o_w2 = sl[f"encoder.{i}.fc1.weight"][0], sl[f"encoder.{i}.fc2.weight"][0]
+            region = o_w2 + blk.fc2.weight.numel() - o_qkv
+            slot = lambda off: ops2.WeightSlot(off, o_qkv, region)  # noqa: E731
             n1 = ops2.layer_norm(h, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
             w = torch.cat((a.queries.weight, a.keys.weight, a.values.weight), dim=0)
             b = torch.cat((a.queries.bias, a.keys.bias, a.values.bias), dim=0)
-            ctx = ops2.attention(ops2.linear(n1, w, b), a.n_attention_heads, 1.0 / float(a.head_embed_dim) ** 0.5)
-            h = h + blk.dropout1(ops2.linear(ctx, a.out_projection.weight, a.out_projection.bias))
+            ctx = ops2.attention(ops2.linear(n1, w, b, slot(o_qkv)), a.n_attention_heads, 1.0 / float(a.head_embed_dim) ** 0.5)
+            h = h + blk.dropout1(ops2.linear(ctx, a.out_projection.weight, a.out_projection.bias, slot(o_wo)))
             n2 = ops2.layer_norm(h, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            z = ops2.act(ops2.linear(n2, blk.fc1.weight, blk.fc1.bias), "gelu")
-            h = h + blk.dropout2(ops2.linear(z, blk.fc2.weight, blk.fc2.bias))
+            z = ops2.act(ops2.linear(n2, blk.fc1.weight, blk.fc1.bias, slot(o_w1)), "gelu")
+            h = h + blk.dropout2(ops2.linear(z, blk.fc2.weight, blk.fc2.bias, slot(o_w2)))
         c = ops2.layer_norm(h[:, 0, :], self.norm.weight, self.norm.bias, self.norm.eps)   # only the CLS row reaches the classifier
         t = ops2.act(ops2.linear(c, self.classifier.fc1.weight, self.classifier.fc1.bias), "tanh")
         # Linear(E, classes_count): E multiply-adds per image and logit - the fused pass has a dedicated kernel for it; here

@@ -46,6 +46,89 @@ class input_grad_only:
         return False
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Deferred, grouped weight gradients.  In the penalty's second backward every Linear of a block gets TWO weight-gradient
+# contributions (dW = dY^T ddX from the backward of its input gradient, and the ordinary dW = dY^T X of its forward under the
+# second-order upstream gradient), at different times: through autograd that is 8 single-problem split-K launches per block,
+# each with its own slab fold and its own AccumulateGrad add (2.9 of the penalty's 9 ms at B = 256).  Inside
+# ``deferred_weight_grads(flat_grad)`` a Linear that was given its ``slot`` in the flat gradient buffer hands autograd None for
+# dW and queues (dY, X) instead; on exit the queue goes out as ONE grouped launch + ONE fold per block and contribution
+# (vg_linear_wgrad_group), accumulating straight into the flat buffer the parameters' .grad are views of.
+# ---------------------------------------------------------------------------------------------------------------------
+_QUEUE = None
+
+
+class WeightSlot:
+    """Where a Linear's weight gradient lives: ``offset`` (elements) into the flat gradient buffer, inside the fold region
+    [``region``, ``region + region_floats``) that the weights of its block tile exactly (flat.vit_slots: wqkv | wo | w1 | w2)."""
+    __slots__ = ("offset", "region", "region_floats")
+
+    def __init__(self, offset: int, region: int, region_floats: int):
+        self.offset, self.region, self.region_floats = int(offset), int(region), int(region_floats)
+
+
+class deferred_weight_grads:
+    """``with ops2.deferred_weight_grads(flat.grad): loss.backward()`` - see above.  The parameters' .grad must be views of
+    ``flat_grad`` (FlatParams.attach_grads): the queued gradients are accumulated into it, not returned to autograd."""
+
+    def __init__(self, flat_grad: torch.Tensor):
+        self.grad, self.items = flat_grad, []
+
+    def __enter__(self):
+        global _QUEUE
+        if _QUEUE is not None:
+            raise RuntimeError("deferred_weight_grads does not nest")
+        _QUEUE = self
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        global _QUEUE
+        _QUEUE = None
+        if exc_type is None:
+            self.flush()
+        self.items = []
+        return False
+
+    def push(self, slot: WeightSlot, dyb: torch.Tensor, xb: torch.Tensor, M: int, N: int, K: int) -> None:
+        self.items.append((slot, dyb, xb, M, N, K))
+
+    def flush(self) -> None:
+        L, st, dev = _lib.lib(), _st(), self.grad.device
+        # contribution index of an item = how many earlier items went to the same weight
+        seen, sets = {}, {}
+        for it in self.items:
+            c = seen.get(it[0].offset, 0)
+            seen[it[0].offset] = c + 1
+            sets.setdefault((it[0].region, it[0].region_floats, c, it[3]), []).append(it)
+        slab = None
+        for (region, rf, _c, M), its in sets.items():
+            tiles = sum(((N + 127) // 128) * max(1, K // 384) for _, _, _, _, N, K in its)
+            covered = sum(N * K for _, _, _, _, N, K in its) == rf and len(its) <= 8
+            if covered:
+                splits = max(1, min(12, 256 // max(tiles, 1), M // 256))
+                need = splits * rf
+                if slab is None or slab.numel() < need:
+                    slab = torch.empty(need, dtype=torch.float32, device=dev)
+                n = len(its)
+                dys = (C.c_void_p * n)(*[t[1].data_ptr() for t in its])
+                xs = (C.c_void_p * n)(*[t[2].data_ptr() for t in its])
+                Ns, Ks = (C.c_int * n)(*[t[4] for t in its]), (C.c_int * n)(*[t[5] for t in its])
+                offs = (C.c_longlong * n)(*[t[0].offset - region for t in its])
+                dst = C.c_void_p(self.grad.data_ptr() + 4 * region)
+                rc = L.vg_linear_wgrad_group(n, dys, xs, Ns, Ks, offs, M, splits, _p(slab), slab.numel(), dst, rf, 1, st)
+                if rc == 0:
+                    continue
+                if rc != -2:  # -2: the items do not tile the region (a frozen weight, a weight used twice): one by one below
+                    _lib.check(rc, "vg_linear_wgrad_group")
+            for slot, dyb, xb, Mi, N, K in its:
+                splits = max(1, min(8, 512 // max(((N + 127) // 128) * ((K + 127) // 128), 1), max(1, (Mi // 64) // 4)))
+                need = splits * N * K
+                if slab is None or slab.numel() < need:
+                    slab = torch.empty(need, dtype=torch.float32, device=dev)
+                _lib.check(L.vg_linear_wgrad(_p(dyb), _p(xb), C.c_void_p(self.grad.data_ptr() + 4 * slot.offset), _p(slab), slab.numel(),
+                                             Mi, N, K, splits, 1, st), "vg_linear_wgrad")
+
+
 def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
@@ -73,7 +156,7 @@ class _LinearDgrad(torch.autograd.Function):
     """dX[M,K] = dY[M,N] W[N,K]  (vg_linear_dgrad); its backward is two more GEMMs."""
 
     @staticmethod
-    def forward(ctx, dy, weight):
+    def forward(ctx, dy, weight, slot=None):
         M, N0 = dy.shape
         K = weight.shape[1]
         N = _pad8(N0)
@@ -83,6 +166,7 @@ class _LinearDgrad(torch.autograd.Function):
         _lib.check(_lib.lib().vg_linear_dgrad(_p(dyb), _p(wb), _p(dx), M, N, K, 0, None, None, 0.0, _st()), "vg_linear_dgrad")
         ctx.save_for_backward(dyb, wb)
         ctx.dims = (M, N, N0, K, dy.dtype)
+        ctx.slot = slot
         return dx.to(dy.dtype)
 
     @staticmethod
@@ -92,15 +176,18 @@ class _LinearDgrad(torch.autograd.Function):
         ub = _bf(ddx)
         d_dy = torch.empty(M, N, dtype=BF, device=ddx.device)   # d(dY) = ddX W^T: the forward Linear kernel
         _lib.check(_lib.lib().vg_linear_fwd(_p(ub), _p(wb), None, None, _p(d_dy), None, None, M, N, K, 0, 0.0, _st()), "vg_linear_fwd")
+        if _QUEUE is not None and ctx.slot is not None and N == N0:
+            _QUEUE.push(ctx.slot, dyb, ub, M, N, K)              # dW = dY^T ddX, grouped with the block's other weights on exit
+            return d_dy.to(dt), None, None
         dW = _wgrad(dyb, ub, M, N, K)[:N0]                       # dW = dY^T ddX: the weight-gradient kernel
-        return d_dy[:, :N0].to(dt), dW
+        return d_dy[:, :N0].to(dt), dW, None
 
 
 class Linear2(torch.autograd.Function):
     """y = x W^T + b, twice differentiable along x and W."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, slot=None):
         _need_cuda(x, "linear")
         K = x.shape[-1]
         N0 = weight.shape[0]
@@ -114,6 +201,7 @@ class Linear2(torch.autograd.Function):
         _lib.check(_lib.lib().vg_linear_fwd(_p(xb), _p(wb), _p(bb), None, _p(y), None, None, M, N, K, 0, 0.0, _st()), "vg_linear_fwd")
         ctx.save_for_backward(xb, weight)
         ctx.dims = (M, N, N0, K, bias is not None, x.shape, x.dtype)
+        ctx.slot = slot
         return y[:, :N0].reshape(x.shape[:-1] + (N0,)).to(x.dtype)
 
     @staticmethod
@@ -121,13 +209,17 @@ class Linear2(torch.autograd.Function):
         xb, weight = ctx.saved_tensors
         M, N, N0, K, has_b, xshape, xdtype = ctx.dims
         dy2 = dy.reshape(M, N0)
-        dx = _LinearDgrad.apply(dy2, weight)                    # differentiable
+        dx = _LinearDgrad.apply(dy2, weight, ctx.slot)          # differentiable
         if _INPUT_GRAD_ONLY:
-            return dx.reshape(xshape).to(xdtype), None, None
+            return dx.reshape(xshape).to(xdtype), None, None, None
         dyb = _pad_cols(_bf(dy2), N)
-        dW = _wgrad(dyb, xb, M, N, K)[:N0]
+        if _QUEUE is not None and ctx.slot is not None and N == N0:
+            _QUEUE.push(ctx.slot, dyb, xb, M, N, K)
+            dW = None
+        else:
+            dW = _wgrad(dyb, xb, M, N, K)[:N0]
         db = _bias_grad(dyb, M, N)[:N0] if has_b else None
-        return dx.reshape(xshape).to(xdtype), dW, db
+        return dx.reshape(xshape).to(xdtype), dW, db, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -288,8 +380,9 @@ class Attention2(torch.autograd.Function):
         return _AttentionBwd.apply(dout, qkv, out, lse, heads, scale), None, None
 
 
-def linear(x, weight, bias=None):
-    return Linear2.apply(x, weight, bias)
+def linear(x, weight, bias=None, slot: Optional[WeightSlot] = None):
+    """``slot``: where this weight's gradient lives in the flat gradient buffer - lets ``deferred_weight_grads`` group it."""
+    return Linear2.apply(x, weight, bias, slot)
 
 
 def layer_norm(x, gamma, beta, eps: float = 1e-5):
