@@ -272,6 +272,10 @@ typedef struct VgVitWsMap {
   long long X, xn1, qkv, ao, xmid, xn2, z1, a1, lse, mean1, rstd1, mean2, rstd2;
   long long gin[2], gmid[2], dqkv[2], dz1[2];
   long long total;
+  /* ABI v7 - the pruned tail of the TOP block: only the CLS rows of its output reach the classifier (modules.py:195), so behind its
+   * attention the block runs on compact [B, E] tensors.  xtop = X[L] on the CLS rows (bf16 [B, E]; the rows of X at L*M*E are not
+   * written any more), dxtop = dL/dX[L] on the CLS rows (bf16 [B, E], exactly zero on every other row; gin[] holds dL/dX[l] for l < L). */
+  long long xtop, dxtop;
 } VgVitWsMap;
 int vg_vit_ws_map(const VgVitDims* d, int B, VgVitWsMap* out);
 

@@ -36,7 +36,7 @@ class VgVitNet(C.Structure):
 
 class VgVitWsMap(C.Structure):
     _fields_ = ([(n, c_ll) for n in ("X", "xn1", "qkv", "ao", "xmid", "xn2", "z1", "a1", "lse", "mean1", "rstd1", "mean2", "rstd2")]
-                + [(n, c_ll * 2) for n in ("gin", "gmid", "dqkv", "dz1")] + [("total", c_ll)])
+                + [(n, c_ll * 2) for n in ("gin", "gmid", "dqkv", "dz1")] + [("total", c_ll), ("xtop", c_ll), ("dxtop", c_ll)])
 
 
 class VgGenWsMap(C.Structure):

@@ -631,6 +631,24 @@ int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStre
                      dscale, dstep);
   return (int)hipGetLastError();
 }
+__global__ __launch_bounds__(256) void vg_scatter_cls2_kernel(const bf16* __restrict__ src_a, bf16* __restrict__ dst_a, const bf16* __restrict__ src_b,
+                                                              bf16* __restrict__ dst_b, int B, int S, int E) {
+  const int cpr = E / 8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * S * cpr) return;
+  const int c = (int)(i % cpr);
+  const long long r = i / cpr;
+  const int b = (int)(r / S), s = (int)(r - (long long)b * S);
+  u32x4 va = {0u, 0u, 0u, 0u}, vb = va;
+  if (s == 0) { va = *(const u32x4*)(src_a + (size_t)b * E + 8 * c); vb = *(const u32x4*)(src_b + (size_t)b * E + 8 * c); }
+  *(u32x4*)(dst_a + (size_t)r * E + 8 * c) = va;
+  *(u32x4*)(dst_b + (size_t)r * E + 8 * c) = vb;
+}
+int vg_scatter_cls2_launch(const bf16* src_a, bf16* dst_a, const bf16* src_b, bf16* dst_b, int B, int S, int E, hipStream_t st) {
+  if ((E & 7) || !src_a || !dst_a || !src_b || !dst_b) return -3;
+  hipLaunchKernelGGL(vg_scatter_cls2_kernel, dim3(nblk((long long)B * S * (E / 8))), dim3(256), 0, st, src_a, dst_a, src_b, dst_b, B, S, E);
+  return (int)hipGetLastError();
+}
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st) {
   if (E & 63) return -3;
   hipLaunchKernelGGL(vg_batch_sum_kernel, dim3(S * (E / 64)), dim3(256), 0, st, g, out, B, S, E);

@@ -225,6 +225,12 @@ struct VitWs {
   bf16 *dxn, *dao, *gp, *dA, *dzh, *dhcls, *dxcls;
   float *part, *part_cs, *hpart, *tok_sum, *slab;
   bf16* wpack;  // E = 384: stage images of Wo | W2 | Wqkv^T | W1^T per block for the full-row GEMMs (gemm_row.hip)
+  // Pruned tail of the TOP block.  The classifier reads the CLS row only (src/v2/modules.py:195), so behind the top block's attention
+  // every row-local operator - out-projection, residual, norm2, fc1, GELU, fc2, residual - matters for the B CLS rows alone, and in the
+  // backward dL/dX[L] is exactly zero on the other 64/65 of the rows: those operators (and their weight gradients) run on compact
+  // [B, .] tensors, forward and backward; the values and gradients the reference defines are unchanged.
+  bf16 *t_xmid, *t_xn2, *t_a1, *t_xtop; unsigned char* t_z1; float *t_mean2, *t_rstd2;
+  bf16 *t_gb2, *t_dz1, *t_dxn2, *t_dxmid, *t_gb1, *t_dao;
 };
 // The full-row GEMMs (LayerNorm in the epilogue) take the block Linears whose output is the embedding when E = 384 and the
 // rows come in whole units of 16; their workgroup count is also the number of LayerNorm-backward partial rows.
@@ -270,6 +276,10 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   if (EMB_SPLIT_CAP * E * Kp > slab) slab = EMB_SPLIT_CAP * E * Kp;
   w.slab = c.take<float>(slab);
   w.wpack = c.take<bf16>(vit_row_nwg(d, (int)M) ? L * lay.layer_weights : 0);
+  w.t_xmid = c.take<bf16>(B * E); w.t_xn2 = c.take<bf16>(B * E); w.t_a1 = c.take<bf16>(B * rE); w.t_xtop = c.take<bf16>(B * E);
+  w.t_z1 = c.take<unsigned char>(B * rE); w.t_mean2 = c.take<float>(B); w.t_rstd2 = c.take<float>(B);
+  w.t_gb2 = c.take<bf16>(B * E); w.t_dz1 = c.take<bf16>(B * rE); w.t_dxn2 = c.take<bf16>(B * E); w.t_dxmid = c.take<bf16>(B * E);
+  w.t_gb1 = c.take<bf16>(B * E); w.t_dao = c.take<bf16>(B * E);
   return c.off;
 }
 extern "C" long long vg_vit_ws_bytes(const VgVitDims* d, int B) {
@@ -292,6 +302,7 @@ extern "C" int vg_vit_ws_map(const VgVitDims* d, int B, VgVitWsMap* o) {
   o->z1 = off(w.z1); o->a1 = off(w.a1); o->lse = off(w.lse);
   o->mean1 = off(w.mean1); o->rstd1 = off(w.rstd1); o->mean2 = off(w.mean2); o->rstd2 = off(w.rstd2);
   for (int i = 0; i < 2; ++i) { o->gin[i] = off(w.set[i].gin); o->gmid[i] = off(w.set[i].gmid); o->dqkv[i] = off(w.set[i].dqkv); o->dz1[i] = off(w.set[i].dz1); }
+  o->xtop = off(w.t_xtop); o->dxtop = off(w.dxcls);
   return 0;
 }
 
@@ -359,6 +370,21 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
                               w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
     VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
+    if (l == d.L - 1) {
+      // Top block: only its CLS rows reach the classifier, so everything behind the attention runs on those B rows (compact tensors;
+      // A = rows b S of `ao`, residual = rows b S of x by their leading dimension; dropout bits = those of rows b S of the full tensor)
+      VgGemmProb po = mk(ao, S * E, Pb + lo + lay.wo, E, B, E, E);
+      po.C = w.t_xmid; po.ldc = E; po.bias = P + lo + lay.bo; po.res = x; po.ldr = S * E;
+      set_drop(po, dr, 1 + 2 * l, 0); po.drop_row_mul = S;
+      VG_TRY(vg_gemm_launch(&po, 1, VG_NT, st));
+      VG_TRY(vg_ln_fwd_launch(w.t_xmid, E, P + lo + lay.ln2_w, P + lo + lay.ln2_b, w.t_xn2, E, w.t_mean2, w.t_rstd2, B, E, 1e-5f, st));
+      VG_TRY(lin_fwd(w.t_xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, w.t_a1, B, rE, VG_ACT_GELU, 0.f, nullptr, (bf16*)w.t_z1, nullptr, st, nullptr, 0, 2));
+      VgGemmProb p2 = mk(w.t_a1, rE, Pb + lo + lay.w2, rE, B, E, rE);
+      p2.C = w.t_xtop; p2.ldc = E; p2.bias = P + lo + lay.b2; p2.res = w.t_xmid; p2.ldr = E;
+      set_drop(p2, dr, 2 + 2 * l, 0); p2.drop_row_mul = S;
+      VG_TRY(vg_gemm_launch(&p2, 1, VG_NT, st));
+      continue;
+    }
     if (rown) {  // x_mid = x + drop(out_projection(ao)) and norm2(x_mid) in one kernel
       VG_TRY(row_fwd(ao, E, wp + po_wo, P + lo + lay.bo, x, xmid, xn2, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M,
                      P + lo + lay.ln2_w, P + lo + lay.ln2_b, 1 + 2 * l));
@@ -382,7 +408,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
-  VG_TRY(vg_ln_fwd_launch(w.X + (size_t)d.L * ME, (long long)S * E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  VG_TRY(vg_ln_fwd_launch(w.t_xtop, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
   VG_TRY(lin_fwd(w.hcls, E, Pb + lay.hw1, P + lay.hb1, w.th, B, E, VG_ACT_TANH, 0.f, nullptr, nullptr, nullptr, st));
   VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
   return 0;
@@ -439,11 +465,11 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
   }
   VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
-  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)d.L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
+  // dL/dX[L] on the CLS rows (it is zero elsewhere) and its masked copy for the top block's MLP dropout - the bits of rows b S of the full tensor
+  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.t_xtop, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, drop ? w.t_gb2 : nullptr, dr.thr,
+                          site_key(dr, 2 + 2 * top), dr.scale, dr.step, st, 1, S));
   if (want_wgrad)  // (the final LayerNorm's own partial count: B rows, standalone kernel; w.part is nobody else's)
     VG_TRY(vg_fold_push(folds, w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0));
-  // dL/dX[L]: the CLS rows, zero elsewhere - and its masked copy for the last block's MLP dropout, in the same launch
-  VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st, drop ? w.set[top & 1].gm2 : nullptr, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step));
   }
 
   int last_side = -1;  // highest-index side event recorded by this call (for the join)
@@ -469,38 +495,57 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     if (split_env > 0 && split_env <= VIT_SPLIT_CAP / 2) splits = split_env;
 #endif
     VgGemmProb pr[8];
+    int np = 0;
     for (int j = 0; j < nb; ++j) {
       const int lb = la - j;
       VitWs::Set& sb = w.set[lb & 1];
       float* slab = w.slab + (size_t)j * splits * lay.layer_weights;
       const bf16* gb1b = drop ? sb.gm1 : sb.gmid;
       const bf16* gb2b = drop ? sb.gm2 : sb.gin;
-      VgGemmProb* q = pr + 4 * j;
-      q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, splits);
-      q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, splits);
-      q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, splits);
-      q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, splits);
       // bias gradients = column sums of the same dY operands: they ride along in the GEMM (ones x A on the MFMA pipe),
       // one row per K slice, folded with the LayerNorm partials at the end.  fc2's bias: only the top block needs it
       // here (lower blocks get it from the LN1 partials of the block above).
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
+      VgGemmProb* q = pr + np;
+      q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, splits);
       q[0].colsum = bs; q[0].colsum_split_stride = BW;
+      if (lb == top) { np += 1; continue; }  // top block: the other three are sums over its B CLS rows (below)
+      q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, splits);
+      q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, splits);
+      q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, splits);
       q[2].colsum = bs + 3 * E; q[2].colsum_split_stride = BW;
-      if (lb == top) { q[3].colsum = bs + 3 * E + rE; q[3].colsum_split_stride = BW; }
+      np += 4;
     }
-    VG_TRY(vg_gemm_launch(pr, 4 * nb, VG_TN, sd));
-    if (nb == 2) {  // both blocks' K slices in one launch
+    VG_TRY(vg_gemm_launch(pr, np, VG_TN, sd));
+    const int ns = pr[0].splits;  // (the launcher drops empty slices; every problem here has the same M rows)
+    if (nb == 2 && la != top) {  // both blocks' K slices in one launch
       const long long lo0 = lay.layer0 + (long long)la * lay.layer_stride, lo1 = lo0 - lay.layer_stride;
-      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, pr[0].splits, G + lo0, G + lo1,
+      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, ns, G + lo0, G + lo1,
                                     lay.layer_weights, 1, sd));
     }
     for (int j = 0; j < nb; ++j) {
       const int lb = la - j;
       const long long lob = lay.layer0 + (long long)lb * lay.layer_stride;
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
-      if (nb == 1) VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lob, lay.layer_weights, 1, sd));
-      VG_TRY(vg_fold_push(folds, bs, pr[4 * j].splits, (int)BW, G + lob + lay.bqkv, 3 * E, G + lob + lay.b1, rE, (lb == top) ? G + lob + lay.b2 : nullptr, E,
-                          nullptr, 0));
+      if (nb == 1 || la == top)  // (the top block's slab holds its QKV part only: wqkv is the first region of a layer)
+        VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, ns, G + lob, lb == top ? 3LL * E * E : lay.layer_weights, 1, sd));
+      VG_TRY(vg_fold_push(folds, bs, ns, (int)BW, G + lob + lay.bqkv, 3 * E, lb == top ? nullptr : G + lob + lay.b1, rE, nullptr, E, nullptr, 0));
+      if (lb != top) continue;
+      // ---- top block: out-projection / fc1 / fc2 weight gradients as sums over the B CLS rows (every other row of their dY is exactly
+      // zero), ONE K slice accumulated straight into the gradient buffer; b1 / b2 ride along as one partial row ----
+      const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
+      const bf16* gb2c = drop ? w.t_gb2 : w.dxcls;
+      float* bsc = bs + (size_t)(VIT_SPLIT_CAP - 1) * BW;  // the last row of the block's carve: the grouped launch above never has 12 slices
+      VgGemmProb c[3];
+      c[0] = wg(gb1c, E, w.ao + (size_t)lb * ME, E, B, G + lob + lay.wo, 0, 1);
+      c[0].ldb = S * E;  // rows b S of the attention output
+      c[1] = wg(w.t_dz1, rE, w.t_xn2, E, B, G + lob + lay.w1, 0, 1);
+      c[2] = wg(gb2c, E, w.t_a1, rE, B, G + lob + lay.w2, 0, 1);
+      for (int i = 0; i < 3; ++i) c[i].cf_accumulate = 1;
+      c[1].colsum = bsc + 3 * E; c[1].colsum_split_stride = BW;
+      c[2].colsum = bsc + 3 * E + rE; c[2].colsum_split_stride = BW;
+      VG_TRY(vg_gemm_launch(c, 3, VG_TN, sd));
+      VG_TRY(vg_fold_push(folds, bsc, 1, (int)BW, nullptr, 3 * E, G + lob + lay.b1, rE, G + lob + lay.b2, E, nullptr, 0));
     }
     return 0;
   };
@@ -524,9 +569,22 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* g = cur.gin;
     const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
     // ---------------- input-gradient chain (main stream) ----------------
+    const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
+    if (l == top) {
+      // Top block, pruned tail: dL/dX[L] lives on the B CLS rows only (w.dxcls; masked copy w.t_gb2), so the MLP half and the
+      // out-projection run on compact [B, .] tensors; their results go back into zero-filled full-size tensors where the
+      // attention backward (d ao) and the QKV input gradient's residual operand (d x_mid) need every row.
+      const bf16* gb2c = drop ? w.t_gb2 : w.dxcls;
+      VG_TRY(lin_dgrad(gb2c, Pb + lo + lay.w2, w.t_dz1, B, E, rE, VG_ACT_MUL_Z8, (const bf16*)w.t_z1, nullptr, 0.f, st));
+      VG_TRY(lin_dgrad(w.t_dz1, Pb + lo + lay.w1, w.t_dxn2, B, rE, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_ln_bwd_launch(w.t_dxn2, w.t_xmid, w.t_mean2, w.t_rstd2, P + lo + lay.ln2_w, w.dxcls, w.t_dxmid, part2, B, E, drop ? w.t_gb1 : nullptr,
+                              dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st, 1, S));
+      const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
+      VG_TRY(lin_dgrad(gb1c, Pb + lo + lay.wo, w.t_dao, B, E, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_scatter_cls2_launch(w.t_dao, w.dao, w.t_dxmid, cur.gmid, B, S, E, st));
+    } else {
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
-    const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
     if (rown) {  // fc1 input gradient + norm2 backward + the residual-stream gradient
       VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid,
                      drop ? cur.gm1 : nullptr, part2, 1 + 2 * l));
@@ -537,6 +595,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     }
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
+    }
     VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     if (!rown) VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     if (pairing) {  // second block of a pair (or the odd one out at the end of this call): its and its partner's weight gradients
@@ -561,7 +620,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
-    VG_TRY(vg_fold_push(folds, part2, lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
+    VG_TRY(vg_fold_push(folds, part2, l == top ? vg_ln_bwd_nparts(B) : lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
     if (!pairing) VG_TRY(wgrad_blocks(l, 1));  // side-stream schedule: block by block, behind the block's input-gradient chain
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
   const float ascale = P.act_scale;
   const int epre = P.pre_f32, rip = P.row_in_per, rop = P.row_out_per, roo = P.row_out_off;
   const unsigned dthr = P.drop_thresh, dkey = vg_drop_key(P.drop_key, P.drop_step); const float dscale = P.drop_scale; const int dpost = P.drop_post;
+  const int drm = P.drop_row_mul > 1 ? P.drop_row_mul : 1;
   const int m0 = cur.m0, n0 = cur.n0, split = cur.split, k_end = cur.k_end;
   const int nsteps = (k_end - cur.k_begin + BK - 1) / BK;
 
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(128 * WM, (vg_gemm_waves<MODE, WM, ACT, FEAT>())) v
       }
       unsigned dw0 = 0, dw1 = 0;
       if (HAS_DROP && dthr) {
-        const unsigned i4 = (unsigned)(mo * eN + n) >> 2;
+        const unsigned i4 = (unsigned)(mo * drm * eN + n) >> 2;
         dw0 = vg_drop_word(dkey, i4); dw1 = vg_drop_word(dkey, i4 + 1);
         if (!dpost) {
 #pragma unroll

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
   const float* const ebias = P.bias;
   const bf16* const eres = NEED_Z ? P.Z : P.res; const int eldr = NEED_Z ? P.ldz : P.ldr;
   const unsigned dthr = P.drop_thresh, dkey = vg_drop_key(P.drop_key, P.drop_step); const float dscale = P.drop_scale;
+  const int drm = P.drop_row_mul > 1 ? P.drop_row_mul : 1;
 
   // ---- A pipeline: stages 0, 1 are in slots 2, 3 (landed with the W load), stage 2 goes to slot 0 now ---------------
   issue4(stage_src(m_begin, 2), voffA, 0);
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
           for (int r = 0; r < 8; ++r) v[r] *= vg_bf2f(pre[qq][r]);
         }
         if (HAS_DROP && dthr) {
-          const unsigned i4 = (unsigned)(m * eN + ncol) >> 2;
+          const unsigned i4 = (unsigned)(m * drm * eN + ncol) >> 2;
           const unsigned dw0 = vg_drop_word(dkey, i4), dw1 = vg_drop_word(dkey, i4 + 1);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] *= vg_drop_factor(dw0, r, dthr, dscale); v[r + 4] *= vg_drop_factor(dw1, r, dthr, dscale); }

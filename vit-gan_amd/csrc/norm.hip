@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
                                                         const float* __restrict__ bs, float* __restrict__ dw_acc,
                                                         int dw_accumulate, int R, bf16* __restrict__ dxm,
                                                         unsigned dthr, unsigned dkey0, float dscale,
-                                                        const unsigned* __restrict__ dstep) {
+                                                        const unsigned* __restrict__ dstep, int drop_row_mul) {
   constexpr int E = NV * 128, CH = 128 / LPR, RPW = 64 / LPR;
   __shared__ float red[3][4][E];
   __shared__ float reds[4][2];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void vg_ln_bwd_kernel(const bf16* __restrict__
       }
       if (ok) *(typename ChunkT<CH>::bt*)(dx + (size_t)rr * E + c) = o;
       if (dxm) {  // gradient entering the dropped branch: dx * mask / keep  (same mask as the forward epilogue)
-        const unsigned i4 = ((unsigned)rr * (unsigned)E + (unsigned)c) >> 2;
+        const unsigned i4 = ((unsigned)(rr * drop_row_mul) * (unsigned)E + (unsigned)c) >> 2;  // (the row of the full tensor this compact row stands for)
 #pragma unroll
         for (int q = 0; q < CH / 4; ++q) {
           const unsigned wd = vg_drop_word(dkey, i4 + q);
@@ -372,12 +372,12 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 int vg_ln_bwd_nparts(int R) { const int n = (R + 15) / 16; return n < LN_MAX_PARTS ? n : LN_MAX_PARTS; }
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
-                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step) {
-  if ((E & 127) || E > 1024 || R < 1 || x_row_step < 1) return -3;
+                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step, int drop_row_mul) {
+  if ((E & 127) || E > 1024 || R < 1 || x_row_step < 1 || drop_row_mul < 1) return -3;
   const int xb = x_row_step > 1 ? -x_row_step : 0;  // row r of the problem reads row x_row_step * r of x (the CLS rows of [B, S, E])
 #define LN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<false, NV_, LN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, x, xb, mean, rstd, gamma, \
                      (const float*)nullptr, gres, dx, part, 3 * E, (const bf16*)nullptr, (const float*)nullptr,                                      \
-                     (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep)
+                     (const float*)nullptr, (float*)nullptr, 0, R, dxm, dthr, dkey, dscale, dstep, drop_row_mul)
   NV_SWITCH(E, LN_BWD)
 #undef LN_BWD
   return (int)hipGetLastError();
@@ -388,7 +388,7 @@ int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf1
                       bf16* dhm, unsigned dthr, unsigned dkey, float dscale, const unsigned* dstep, hipStream_t st) {
   if ((E & 127) || E > 1024 || R < 1) return -3;
 #define SLN_BWD(NV_) hipLaunchKernelGGL((vg_ln_bwd_kernel<true, NV_, SLN_BWD_LPR>), dim3(vg_ln_bwd_nparts(R)), dim3(256), 0, st, dy, h, h_bcast_rows, mean, \
-                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, dhm, dthr, dkey, dscale, dstep)
+                     rstd, lw, lb, gres, dh, part, 3 * E + 64, wmod, gs, bs, dw_acc, dw_accumulate, R, dhm, dthr, dkey, dscale, dstep, 1)
   NV_SWITCH(E, SLN_BWD)
 #undef SLN_BWD
   return (int)hipGetLastError();

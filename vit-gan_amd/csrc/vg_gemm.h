@@ -45,6 +45,8 @@ struct VgGemmProb {
   // dropout on the output (NT only): drop_thresh = round(p*256) (0 = off); applied after bias/activation and BEFORE
   // the residual (drop_post = 0: x + drop(y)) or after every addend (drop_post = 1: drop(y + pos)); index = row*N + col
   unsigned drop_thresh, drop_key; float drop_scale; int drop_post; const unsigned* drop_step;
+  int drop_row_mul;            // > 1: the mask index is (row * drop_row_mul) * N + col - a compact [B, N] problem over rows 0, S, 2S, ..
+                               // of a [B*S, N] tensor (the CLS rows) draws exactly the bits the full-size launch would have drawn there
   // TN only: column sums of A over k (= the bias gradient that goes with this weight gradient), one fp32 row [M] per
   // K slice at colsum + s*colsum_split_stride (nullable).  Computed on the MFMA pipe (ones x A fragments) by the
   // workgroups of the first n-tile: the wgrad kernel is L2->LDS bound, the extra MFMAs are free.

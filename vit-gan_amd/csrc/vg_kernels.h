@@ -15,7 +15,7 @@ int vg_sln_fwd_launch(const bf16* h, int h_bcast_rows, const bf16* wmod, const f
 int vg_ln_bwd_nparts(int R);
 int vg_ln_bwd_launch(const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, float* part, int R, int E, bf16* dxm, unsigned dthr, unsigned dkey,
-                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step = 1);
+                     float dscale, const unsigned* dstep, hipStream_t st, int x_row_step = 1, int drop_row_mul = 1);  // drop_row_mul: dxm's mask is that of row r * drop_row_mul of the full tensor
 int vg_sln_bwd_launch(const bf16* dy, const bf16* h, int h_bcast_rows, const bf16* wmod, const float* mean,
                       const float* rstd, const float* lw, const float* lb, const float* gs, const float* bs,
                       const bf16* gres, bf16* dh, float* dw_acc, int dw_accumulate, float* part, int R, int E,
@@ -41,6 +41,8 @@ int vg_take_rows_launch(const bf16* in, bf16* out, int B, int S, int first, int 
 // gm (nullable): the same rows times the dropout mask of site key dkey over the [B*S, E] buffer (what vg_dropout_apply would make of g)
 int vg_scatter_cls_launch(const bf16* src, bf16* g, int B, int S, int E, hipStream_t st, bf16* gm = nullptr, unsigned dthr = 0, unsigned dkey = 0,
                           float dscale = 1.f, const unsigned* dstep = nullptr);
+// two compact [B, E] sources into the CLS rows of two zero-filled [B*S, E] tensors, one launch (the pruned tail of the top encoder block)
+int vg_scatter_cls2_launch(const bf16* src_a, bf16* dst_a, const bf16* src_b, bf16* dst_b, int B, int S, int E, hipStream_t st);
 int vg_batch_sum_launch(const bf16* g, float* out, int B, int S, int E, hipStream_t st);
 int vg_embed_small_grads_launch(const float* tok_sum, float* d_cls, float* d_pos, float* d_bias, int S, int E, hipStream_t st);
 int vg_head_fc2_launch(const bf16* t, const float* W2, const float* b2, float* logits, int B, int E, int Kc, hipStream_t st);
