@@ -152,6 +152,13 @@ int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S
                      float scale, void* stream);
 int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
                      void* d_qkv, int B, int H, int S, int HE, float scale, void* stream);
+/* The same attention for ONE query per image, row 0 (ABI v7): what the classifier sees of the top encoder block
+ * (src/v2/modules.py:195 reads the CLS row only).  out_cls / d_out_cls bf16 [B, H*HE] (the CLS rows, compact), lse_cls fp32
+ * [B, H]; d_qkv is the full [B*S, 3*H*HE] gradient (dK, dV of every key, dQ zero off row 0) - exactly what vg_attention_bwd
+ * writes when d_out is zero on every other row.  S <= 128. */
+int vg_attention_cls_fwd(const void* qkv, void* out_cls, float* lse_cls, int B, int H, int S, int HE, float scale, void* stream);
+int vg_attention_cls_bwd(const void* qkv, const void* out_cls, const void* d_out_cls, const float* lse_cls, void* d_qkv, int B, int H,
+                         int S, int HE, float scale, void* stream);
 
 /* The same fused attention with the v1 discriminator's L2-distance scores (src/v1/attention.py:43-52,66-67, lp = 2):
  * out = softmax(cdist(q, k) * scale) @ v - the Euclidean distance itself, as the reference has it.  Same layouts. */

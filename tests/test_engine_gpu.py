@@ -33,7 +33,10 @@ def test_engine_step_matches_oracle(loss, fuse):
     B = 8
     D, G, oracle = _build(B, loss)
     eng = GanEngine(D, G, batch=B, loss=loss, fuse_real_fake=fuse)
-    g = torch.Generator().manual_seed(0)
+    # hinge: not seed 0 - with it every fake logit of step 0 sits below -1, the fake half's gradient is EXACTLY zero, most of D's first
+    # AdamW step is lr * sign(rounding noise), and the step-1 generator loss is decided by that noise: 0.017-0.052 off the oracle across
+    # schedules and kernel versions (tools/micro/step_dev.py), against 0.001-0.005 for every other seed and for the ns loss
+    g = torch.Generator().manual_seed(0 if loss == "ns" else 1)
     for it in range(2):
         real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
         losses = eng.step(real.cuda())

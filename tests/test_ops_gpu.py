@@ -337,6 +337,49 @@ def test_attention(B, H, S, HE, scale):
         u.assert_close(dQKV[:, i * E:(i + 1) * E], qkv.grad[:, i * E:(i + 1) * E], 2.0 ** -5, f"d{nm}")
 
 
+@pytest.mark.parametrize("B,H,S,HE", [(3, 4, 65, 96), (16, 4, 65, 96), (2, 8, 65, 64), (2, 12, 65, 64), (5, 2, 17, 32), (2, 4, 80, 96)])
+def test_attention_cls_query(B, H, S, HE):
+    """The top block's attention as the classifier sees it (one query per image, row 0): against fp32 attention, and against the
+    full kernels at that row - the forward's row 0, and the backward fed a d_out that is zero on every other row."""
+    u = _u()
+    E, scale = H * HE, 1 / math.sqrt(HE)
+    g = torch.Generator().manual_seed(B + H + S + HE)
+    qkv = u.rbf(torch.randn(B * S, 3 * E, generator=g) * 1.5).requires_grad_(True)
+    dO0 = u.rbf(torch.randn(B, E, generator=g))
+    q, k, v = (qkv[:, i * E:(i + 1) * E].reshape(B, S, H, HE).transpose(1, 2) for i in range(3))
+    sc = (q[:, :, :1] @ k.transpose(-1, -2)) * scale                       # [B, H, 1, S]
+    o0 = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, E)
+    lse_ref = torch.logsumexp(sc, -1).reshape(B, H)
+    QKV = u.dev(qkv.detach(), u.BF)
+    Oc = torch.empty(B, E, dtype=u.BF, device="cuda")
+    Lc = torch.empty(B, H, device="cuda")
+    u.call("vg_attention_cls_fwd", u.ptr(QKV), u.ptr(Oc), u.ptr(Lc), B, H, S, HE, scale, u.stream())
+    u.sync()
+    u.assert_close(Lc, lse_ref, 1e-4, "lse of the CLS query")
+    u.assert_close(Oc, o0, 2.0 ** -6, "attention output of the CLS query")
+    o0.backward(dO0)
+    DOc = u.dev(dO0, u.BF)
+    dQKV = torch.full((B * S, 3 * E), 7.0, dtype=u.BF, device="cuda")
+    u.call("vg_attention_cls_bwd", u.ptr(QKV), u.ptr(Oc), u.ptr(DOc), u.ptr(Lc), u.ptr(dQKV), B, H, S, HE, scale, u.stream())
+    u.sync()
+    for i, nm in enumerate("qkv"):
+        u.assert_close(dQKV[:, i * E:(i + 1) * E], qkv.grad[:, i * E:(i + 1) * E], 2.0 ** -5, f"d{nm} (CLS query)")
+    dq = dQKV[:, :E].reshape(B, S, E)
+    assert bool((dq[:, 1:] == 0).all()), "dQ must be exactly zero off the CLS rows"
+    if S <= 80:  # the full kernels' range: same operator, same roundings - row 0 of the forward, d_out zero elsewhere in the backward
+        O = torch.empty(B * S, E, dtype=u.BF, device="cuda")
+        LSE = torch.empty(B, H, S, device="cuda")
+        u.call("vg_attention_fwd", u.ptr(QKV), u.ptr(O), u.ptr(LSE), B, H, S, HE, scale, u.stream())
+        DO = torch.zeros(B, S, E, dtype=u.BF, device="cuda")
+        DO[:, 0] = DOc
+        dFull = torch.empty(B * S, 3 * E, dtype=u.BF, device="cuda")
+        u.call("vg_attention_bwd", u.ptr(QKV), u.ptr(O), u.ptr(DO), u.ptr(LSE), u.ptr(dFull), B, H, S, HE, scale, u.stream())
+        u.sync()
+        u.assert_close(Oc, O.reshape(B, S, E)[:, 0].float().cpu(), 2.0 ** -8, "forward vs the full kernel's row 0")
+        u.assert_close(Lc, LSE[:, :, 0].cpu(), 1e-5, "lse vs the full kernel's")
+        u.assert_close(dQKV, dFull.float().cpu(), 2.0 ** -7, "backward vs the full kernel with d_out zero off the CLS rows")
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("role", [0, 1, 2])
 def test_gan_loss(kind, role):

@@ -88,6 +88,8 @@ _SIGNATURES = {
     "vg_dropout_apply": (c_int, [P, P, c_ll, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_attention_cls_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "vg_attention_cls_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "vg_unfold_tokens_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vg_unfold_tokens_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vg_attention_fp8_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),

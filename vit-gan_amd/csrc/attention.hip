@@ -878,6 +878,164 @@ int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const fl
   VG_ATTN_DISPATCH(launch_bwd, qkv, o, d_o, lse, dqkv, B, H, S, scale, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention of the TOP encoder block as the classifier sees it (src/v2/modules.py:195 reads the CLS row only): ONE query - row 0 of
+// every image - against all S keys.  Forward: o_cls[b, h*HE ..] = softmax(s q0 K^T) V; backward: dO is nonzero for that query
+// only, so dK_j = ds_j q0, dV_j = p_j dO_0 are rank-one and dQ is zero off row 0.  Same arithmetic as the full kernels at that
+// row (fp32 scores of bf16 operands, p and ds rounded to bf16 where the full kernels make them MFMA operands, 1 / l applied to
+// the fp32 sum), 1/65 of their products and half their bytes (K and V in, dK and dV out).  One wave per (image, head): lanes over
+// the keys for the scores (a lane reads its K / V row in 16-byte chunks), lanes over the head dimension for the two reductions
+// over keys (o, dQ), with p / ds passed through LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HE>
+__global__ __launch_bounds__(64) void vg_attn_cls_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o_cls, float* __restrict__ lse_cls,
+                                                             int B, int S, int H, float scale) {
+  constexpr int CPR = HE / 8;
+  __shared__ float pl[128];
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
+  const int lane = threadIdx.x;
+  const int E = H * HE;
+  const size_t ld = 3 * (size_t)E;
+  const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
+  const bf16* kb = qb + E;
+  const bf16* vb = qb + 2 * E;
+  bf16x8 q0[CPR];  // the query, in every lane (one address: a broadcast load)
+#pragma unroll
+  for (int c = 0; c < CPR; ++c) q0[c] = *(const bf16x8*)(qb + 8 * c);
+  float sv[2];
+#pragma unroll
+  for (int rnd = 0; rnd < 2; ++rnd) {
+    const int j = lane + 64 * rnd;
+    float a = 0.f;
+    if (j < S) {
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {
+        const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)j * ld + 8 * c);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a = fmaf(vg_bf2f(q0[c][t]), vg_bf2f(k8[t]), a);
+      }
+    }
+    sv[rnd] = (j < S) ? a * scale : -INFINITY;
+  }
+  const float m = vg_wave_max(fmaxf(sv[0], sv[1]));
+  const float p0 = __expf(sv[0] - m), p1 = __expf(sv[1] - m);  // exp(-inf) = 0 for the padded keys
+  const float l = vg_wave_sum(p0 + p1);
+  pl[lane] = vg_bf2f(vg_f2bf(p0));       // the full kernel multiplies V by bf16(p) (an MFMA operand) and divides the fp32 sum by l
+  pl[lane + 64] = vg_bf2f(vg_f2bf(p1));
+  if (lane == 0) lse_cls[(size_t)b * H + h] = m + __logf(l);
+  __syncthreads();
+  // o[d] = sum_j p_j V[j][d] / l: lanes over pairs of the head dimension
+  const float inv_l = 1.0f / l;
+  if (lane < HE / 2) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const bf16x2 v2 = *(const bf16x2*)(vb + (size_t)j * ld + 2 * lane);
+      const float pj = pl[j];
+      a0 = fmaf(pj, vg_bf2f(v2[0]), a0);
+      a1 = fmaf(pj, vg_bf2f(v2[1]), a1);
+    }
+    bf16x2 ov; ov[0] = vg_f2bf(a0 * inv_l); ov[1] = vg_f2bf(a1 * inv_l);
+    *(bf16x2*)(o_cls + (size_t)b * E + h * HE + 2 * lane) = ov;
+  }
+}
+
+template <int HE>
+__global__ __launch_bounds__(64) void vg_attn_cls_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_cls, const bf16* __restrict__ do_cls,
+                                                             const float* __restrict__ lse_cls, bf16* __restrict__ dqkv, int B, int S, int H,
+                                                             float scale) {
+  constexpr int CPR = HE / 8;
+  __shared__ float dsl[128];
+  int b, h;
+  if (!attn_block(B, H, b, h)) return;
+  const int lane = threadIdx.x;
+  const int E = H * HE;
+  const size_t ld = 3 * (size_t)E;
+  const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
+  const bf16* kb = qb + E;
+  const bf16* vb = qb + 2 * E;
+  bf16* dqb = dqkv + (size_t)b * S * ld + h * HE;
+  const float lse0 = lse_cls[(size_t)b * H + h];
+  bf16x8 q0[CPR], d0[CPR];
+  float delta = 0.f;  // sum_d dO_0[d] O_0[d], the same in every lane
+#pragma unroll
+  for (int c = 0; c < CPR; ++c) {
+    q0[c] = *(const bf16x8*)(qb + 8 * c);
+    d0[c] = *(const bf16x8*)(do_cls + (size_t)b * E + h * HE + 8 * c);
+    const bf16x8 o8 = *(const bf16x8*)(o_cls + (size_t)b * E + h * HE + 8 * c);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) delta = fmaf(vg_bf2f(d0[c][t]), vg_bf2f(o8[t]), delta);
+  }
+#pragma unroll
+  for (int rnd = 0; rnd < 2; ++rnd) {
+    const int j = lane + 64 * rnd;
+    float dsv = 0.f;
+    if (j < S) {
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {
+        const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)j * ld + 8 * c);
+        const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * ld + 8 * c);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          sc = fmaf(vg_bf2f(q0[c][t]), vg_bf2f(k8[t]), sc);
+          dp = fmaf(vg_bf2f(d0[c][t]), vg_bf2f(v8[t]), dp);
+        }
+      }
+      const float p = __expf(sc * scale - lse0);
+      dsv = vg_bf2f(vg_f2bf(p * (dp - delta) * scale));  // bf16: an MFMA operand in the full kernel
+      const float pb = vg_bf2f(vg_f2bf(p));
+      // the key's rows of dK and dV: rank one in the CLS query
+      bf16* rowp = dqb + (size_t)j * ld;
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {
+        bf16x8 dk8, dv8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { dk8[t] = vg_f2bf(dsv * vg_bf2f(q0[c][t])); dv8[t] = vg_f2bf(pb * vg_bf2f(d0[c][t])); }
+        *(bf16x8*)(rowp + E + 8 * c) = dk8;
+        *(bf16x8*)(rowp + 2 * E + 8 * c) = dv8;
+      }
+    }
+    dsl[j] = dsv;
+  }
+  __syncthreads();
+  // dQ: row 0 = sum_j ds_j K_j, every other row zero
+  if (lane < HE / 2) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const bf16x2 k2 = *(const bf16x2*)(kb + (size_t)j * ld + 2 * lane);
+      const float dj = dsl[j];
+      a0 = fmaf(dj, vg_bf2f(k2[0]), a0);
+      a1 = fmaf(dj, vg_bf2f(k2[1]), a1);
+    }
+    bf16x2 dq2; dq2[0] = vg_f2bf(a0); dq2[1] = vg_f2bf(a1);
+    *(bf16x2*)(dqb + 2 * lane) = dq2;
+  }
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int i = lane; i < (S - 1) * CPR; i += 64) {
+    const int r = 1 + i / CPR, c = i - (r - 1) * CPR;
+    *(u32x4*)(dqb + (size_t)r * ld + 8 * c) = z;
+  }
+}
+
+// o_cls / do_cls: [B, E] (the CLS rows, compact); lse_cls: [B, H]; dqkv: the full [B*S, 3E] gradient.  Dot-product scores only
+// (the engine keeps the full kernels for the top block when the fp8 mode is on); -3: head dim not 32 / 64 / 96.
+int vg_attn_cls_fwd_launch(const bf16* qkv, bf16* o_cls, float* lse_cls, int B, int H, int S, int HE, float scale, hipStream_t st) {
+  if (S < 1 || S > 128 || B < 1 || H < 1) return -2;
+#define VG_ACLS(HE_) hipLaunchKernelGGL((vg_attn_cls_fwd_kernel<HE_>), dim3(attn_grid(B, H)), dim3(64), 0, st, qkv, o_cls, lse_cls, B, S, H, scale)
+  if (HE == 96) VG_ACLS(96); else if (HE == 64) VG_ACLS(64); else if (HE == 32) VG_ACLS(32); else return -3;
+#undef VG_ACLS
+  return (int)hipGetLastError();
+}
+int vg_attn_cls_bwd_launch(const bf16* qkv, const bf16* o_cls, const bf16* do_cls, const float* lse_cls, bf16* dqkv, int B, int H, int S, int HE,
+                           float scale, hipStream_t st) {
+  if (S < 1 || S > 128 || B < 1 || H < 1) return -2;
+#define VG_ACLS(HE_) hipLaunchKernelGGL((vg_attn_cls_bwd_kernel<HE_>), dim3(attn_grid(B, H)), dim3(64), 0, st, qkv, o_cls, do_cls, lse_cls, dqkv, B, S, H, scale)
+  if (HE == 96) VG_ACLS(96); else if (HE == 64) VG_ACLS(64); else if (HE == 32) VG_ACLS(32); else return -3;
+#undef VG_ACLS
+  return (int)hipGetLastError();
+}
+
 // the second-order kernel above (S <= 80: padded to five 16-row tiles); -3: head dim not 32 / 64 / 96
 int vg_attn_bwd_bwd_mfma_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
                                 int S, int HE, float scale, hipStream_t st) {

@@ -195,6 +195,16 @@ extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   if (!qkv || !out || !lse) return -1;
   return vg_attn_fwd_launch((const bf16*)qkv, (bf16*)out, lse, B, H, S, HE, scale, 0, (hipStream_t)stream);
 }
+extern "C" int vg_attention_cls_fwd(const void* qkv, void* out_cls, float* lse_cls, int B, int H, int S, int HE, float scale, void* stream) {
+  if (!qkv || !out_cls || !lse_cls) return -1;
+  return vg_attn_cls_fwd_launch((const bf16*)qkv, (bf16*)out_cls, lse_cls, B, H, S, HE, scale, (hipStream_t)stream);
+}
+extern "C" int vg_attention_cls_bwd(const void* qkv, const void* out_cls, const void* d_out_cls, const float* lse_cls, void* d_qkv, int B, int H,
+                                    int S, int HE, float scale, void* stream) {
+  if (!qkv || !out_cls || !d_out_cls || !lse_cls || !d_qkv) return -1;
+  return vg_attn_cls_bwd_launch((const bf16*)qkv, (const bf16*)out_cls, (const bf16*)d_out_cls, lse_cls, (bf16*)d_qkv, B, H, S, HE, scale,
+                                (hipStream_t)stream);
+}
 extern "C" int vg_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* d_qkv, int B, int H,
                                 int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !d_out || !lse || !d_qkv) return -1;

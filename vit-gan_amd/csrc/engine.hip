@@ -231,6 +231,7 @@ struct VitWs {
   // [B, .] tensors, forward and backward; the values and gradients the reference defines are unchanged.
   bf16 *t_xmid, *t_xn2, *t_a1, *t_xtop; unsigned char* t_z1; float *t_mean2, *t_rstd2;
   bf16 *t_gb2, *t_dz1, *t_dxn2, *t_dxmid, *t_gb1, *t_dao;
+  bf16* t_ao; float* t_lse;  // and its attention for the CLS query only (dot-product scores; the fp8 mode keeps the full kernels)
 };
 // The full-row GEMMs (LayerNorm in the epilogue) take the block Linears whose output is the embedding when E = 384 and the
 // rows come in whole units of 16; their workgroup count is also the number of LayerNorm-backward partial rows.
@@ -280,6 +281,7 @@ static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   w.t_z1 = c.take<unsigned char>(B * rE); w.t_mean2 = c.take<float>(B); w.t_rstd2 = c.take<float>(B);
   w.t_gb2 = c.take<bf16>(B * E); w.t_dz1 = c.take<bf16>(B * rE); w.t_dxn2 = c.take<bf16>(B * E); w.t_dxmid = c.take<bf16>(B * E);
   w.t_gb1 = c.take<bf16>(B * E); w.t_dao = c.take<bf16>(B * E);
+  w.t_ao = c.take<bf16>(B * E); w.t_lse = c.take<float>((long long)B * d.H);
   return c.off;
 }
 extern "C" long long vg_vit_ws_bytes(const VgVitDims* d, int B) {
@@ -369,11 +371,13 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
       VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
                               w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
+    const bool cls_attn = (l == d.L - 1) && !net->attn_fp8;  // top block: the CLS query is the only one the classifier sees
+    if (cls_attn) VG_TRY(vg_attn_cls_fwd_launch(qkv, w.t_ao, w.t_lse, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    else VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     if (l == d.L - 1) {
       // Top block: only its CLS rows reach the classifier, so everything behind the attention runs on those B rows (compact tensors;
       // A = rows b S of `ao`, residual = rows b S of x by their leading dimension; dropout bits = those of rows b S of the full tensor)
-      VgGemmProb po = mk(ao, S * E, Pb + lo + lay.wo, E, B, E, E);
+      VgGemmProb po = cls_attn ? mk(w.t_ao, E, Pb + lo + lay.wo, E, B, E, E) : mk(ao, S * E, Pb + lo + lay.wo, E, B, E, E);
       po.C = w.t_xmid; po.ldc = E; po.bias = P + lo + lay.bo; po.res = x; po.ldr = S * E;
       set_drop(po, dr, 1 + 2 * l, 0); po.drop_row_mul = S;
       VG_TRY(vg_gemm_launch(&po, 1, VG_NT, st));
@@ -537,8 +541,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       const bf16* gb2c = drop ? w.t_gb2 : w.dxcls;
       float* bsc = bs + (size_t)(VIT_SPLIT_CAP - 1) * BW;  // the last row of the block's carve: the grouped launch above never has 12 slices
       VgGemmProb c[3];
-      c[0] = wg(gb1c, E, w.ao + (size_t)lb * ME, E, B, G + lob + lay.wo, 0, 1);
-      c[0].ldb = S * E;  // rows b S of the attention output
+      if (!net->attn_fp8) c[0] = wg(gb1c, E, w.t_ao, E, B, G + lob + lay.wo, 0, 1);  // the CLS query's attention output
+      else { c[0] = wg(gb1c, E, w.ao + (size_t)lb * ME, E, B, G + lob + lay.wo, 0, 1); c[0].ldb = S * E; }  // rows b S of the full one
       c[1] = wg(w.t_dz1, rE, w.t_xn2, E, B, G + lob + lay.w1, 0, 1);
       c[2] = wg(gb2c, E, w.t_a1, rE, B, G + lob + lay.w2, 0, 1);
       for (int i = 0; i < 3; ++i) c[i].cf_accumulate = 1;
@@ -581,7 +585,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
                               dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st, 1, S));
       const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
       VG_TRY(lin_dgrad(gb1c, Pb + lo + lay.wo, w.t_dao, B, E, E, 0, nullptr, nullptr, 0.f, st));
-      VG_TRY(vg_scatter_cls2_launch(w.t_dao, w.dao, w.t_dxmid, cur.gmid, B, S, E, st));
+      if (!net->attn_fp8) VG_TRY(vg_scatter_cls_launch(w.t_dxmid, cur.gmid, B, S, E, st));  // (d ao stays compact: the CLS-query attention backward below)
+      else VG_TRY(vg_scatter_cls2_launch(w.t_dao, w.dao, w.t_dxmid, cur.gmid, B, S, E, st));
     } else {
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
@@ -596,7 +601,10 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     }
-    VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
+    if (l == top && !net->attn_fp8)
+      VG_TRY(vg_attn_cls_bwd_launch(qkv, w.t_ao, w.t_dao, w.t_lse, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
+    else
+      VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
     if (!rown) VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     if (pairing) {  // second block of a pair (or the odd one out at the end of this call): its and its partner's weight gradients
       const int idx = l_hi - l;

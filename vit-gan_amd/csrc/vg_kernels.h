@@ -86,6 +86,10 @@ int vg_act2_launch(const bf16* h, const bf16* dy, const bf16* u, bf16* o0, bf16*
 int vg_ln_bwd_bwd_nparts(int R);
 int vg_ln_bwd_bwd_launch(const bf16* u, const bf16* dy, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                          bf16* d_dy, bf16* d_x, float* part, int R, int E, hipStream_t st);
+// the top block's attention as the classifier sees it: the CLS query only (attention.hip); o_cls / do_cls [B, E], lse_cls [B, H]
+int vg_attn_cls_fwd_launch(const bf16* qkv, bf16* o_cls, float* lse_cls, int B, int H, int S, int HE, float scale, hipStream_t st);
+int vg_attn_cls_bwd_launch(const bf16* qkv, const bf16* o_cls, const bf16* do_cls, const float* lse_cls, bf16* dqkv, int B, int H, int S, int HE,
+                           float scale, hipStream_t st);
 int vg_attn_bwd_bwd_mfma_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
                                 int S, int HE, float scale, hipStream_t st);  // attention.hip
 int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, const bf16* uqkv, bf16* d_do, bf16* d_qkv, int B, int H,
