@@ -883,26 +883,45 @@ int vg_attn_bwd_launch(const bf16* qkv, const bf16* o, const bf16* d_o, const fl
 // every image - against all S keys.  Forward: o_cls[b, h*HE ..] = softmax(s q0 K^T) V; backward: dO is nonzero for that query
 // only, so dK_j = ds_j q0, dV_j = p_j dO_0 are rank-one and dQ is zero off row 0.  Same arithmetic as the full kernels at that
 // row (fp32 scores of bf16 operands, p and ds rounded to bf16 where the full kernels make them MFMA operands, 1 / l applied to
-// the fp32 sum), 1/65 of their products and half their bytes (K and V in, dK and dV out).  One wave per (image, head): lanes over
-// the keys for the scores (a lane reads its K / V row in 16-byte chunks), lanes over the head dimension for the two reductions
-// over keys (o, dQ), with p / ds passed through LDS.
+// the fp32 sum), 1/65 of their products and half their bytes (K and V in, dK and dV out).  One wave per (image, head).  (A first
+// version with lanes over the KEYS - a lane reading and writing its own rows in 16-byte chunks, 64 row segments per instruction -
+// took 65 us for the 2B backward, more than the full kernel's 57.)
 // ---------------------------------------------------------------------------------------------------------------------
+// Work layout of both kernels: a wave walks the head's K / V rows RPI at a time, lane = (row rr = lane / CPR, 16-byte chunk c = lane % CPR),
+// so every load and store of a wave-instruction covers RPI whole 2 HE-byte row segments (HE = 96: 60 of the 64 lanes, 5 rows).
 template <int HE>
 __global__ __launch_bounds__(64) void vg_attn_cls_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o_cls, float* __restrict__ lse_cls,
                                                              int B, int S, int H, float scale) {
-  constexpr int CPR = HE / 8;
+  constexpr int CPR = HE / 8, RPI = 64 / CPR;
+  __shared__ float q0l[HE];
+  __shared__ float part[128 * CPR];  // per (key, chunk) partial dot products; then the per-lane partial outputs
   __shared__ float pl[128];
   int b, h;
   if (!attn_block(B, H, b, h)) return;
   const int lane = threadIdx.x;
+  const int rr = lane / CPR, c = lane - rr * CPR;
+  const bool act = rr < RPI;
   const int E = H * HE;
   const size_t ld = 3 * (size_t)E;
   const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
   const bf16* kb = qb + E;
   const bf16* vb = qb + 2 * E;
-  bf16x8 q0[CPR];  // the query, in every lane (one address: a broadcast load)
+  for (int d = lane; d < HE; d += 64) q0l[d] = vg_bf2f(qb[d]);
+  __syncthreads();
+  float qc[8];
 #pragma unroll
-  for (int c = 0; c < CPR; ++c) q0[c] = *(const bf16x8*)(qb + 8 * c);
+  for (int t = 0; t < 8; ++t) qc[t] = q0l[8 * (act ? c : 0) + t];
+  for (int r0 = 0; r0 < S; r0 += RPI) {
+    const int r = r0 + rr;
+    if (act && r < S) {
+      const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)r * ld + 8 * c);
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a = fmaf(qc[t], vg_bf2f(k8[t]), a);
+      part[r * CPR + c] = a;
+    }
+  }
+  __syncthreads();
   float sv[2];
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
@@ -910,11 +929,7 @@ __global__ __launch_bounds__(64) void vg_attn_cls_fwd_kernel(const bf16* __restr
     float a = 0.f;
     if (j < S) {
 #pragma unroll
-      for (int c = 0; c < CPR; ++c) {
-        const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)j * ld + 8 * c);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) a = fmaf(vg_bf2f(q0[c][t]), vg_bf2f(k8[t]), a);
-      }
+      for (int cc = 0; cc < CPR; ++cc) a += part[j * CPR + cc];
     }
     sv[rnd] = (j < S) ? a * scale : -INFINITY;
   }
@@ -925,18 +940,28 @@ __global__ __launch_bounds__(64) void vg_attn_cls_fwd_kernel(const bf16* __restr
   pl[lane + 64] = vg_bf2f(vg_f2bf(p1));
   if (lane == 0) lse_cls[(size_t)b * H + h] = m + __logf(l);
   __syncthreads();
-  // o[d] = sum_j p_j V[j][d] / l: lanes over pairs of the head dimension
-  const float inv_l = 1.0f / l;
-  if (lane < HE / 2) {
-    float a0 = 0.f, a1 = 0.f;
-    for (int j = 0; j < S; ++j) {
-      const bf16x2 v2 = *(const bf16x2*)(vb + (size_t)j * ld + 2 * lane);
-      const float pj = pl[j];
-      a0 = fmaf(pj, vg_bf2f(v2[0]), a0);
-      a1 = fmaf(pj, vg_bf2f(v2[1]), a1);
+  // o[d] = sum_j p_j V[j][d] / l: every lane sums its chunk over its rows, then the RPI row slots are added up through LDS
+  float oa[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) oa[t] = 0.f;
+  for (int r0 = 0; r0 < S; r0 += RPI) {
+    const int r = r0 + rr;
+    if (act && r < S) {
+      const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)r * ld + 8 * c);
+      const float pj = pl[r];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) oa[t] = fmaf(pj, vg_bf2f(v8[t]), oa[t]);
     }
-    bf16x2 ov; ov[0] = vg_f2bf(a0 * inv_l); ov[1] = vg_f2bf(a1 * inv_l);
-    *(bf16x2*)(o_cls + (size_t)b * E + h * HE + 2 * lane) = ov;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) part[lane * 8 + t] = oa[t];
+  __syncthreads();
+  const float inv_l = 1.0f / l;
+  for (int d = lane; d < HE; d += 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPI; ++q) a += part[(q * CPR + (d >> 3)) * 8 + (d & 7)];
+    o_cls[(size_t)b * E + h * HE + d] = vg_f2bf(a * inv_l);
   }
 }
 
@@ -944,11 +969,15 @@ template <int HE>
 __global__ __launch_bounds__(64) void vg_attn_cls_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_cls, const bf16* __restrict__ do_cls,
                                                              const float* __restrict__ lse_cls, bf16* __restrict__ dqkv, int B, int S, int H,
                                                              float scale) {
-  constexpr int CPR = HE / 8;
-  __shared__ float dsl[128];
+  constexpr int CPR = HE / 8, RPI = 64 / CPR;
+  __shared__ float q0l[HE], d0l[HE];
+  __shared__ float ps[128 * CPR], pd[128 * CPR];  // per (key, chunk) partial dot products q0.K and dO0.V; ps then holds the partial dQ
+  __shared__ float dsl[128], pbl[128];
   int b, h;
   if (!attn_block(B, H, b, h)) return;
   const int lane = threadIdx.x;
+  const int rr = lane / CPR, c = lane - rr * CPR;
+  const bool act = rr < RPI;
   const int E = H * HE;
   const size_t ld = 3 * (size_t)E;
   const bf16* qb = qkv + (size_t)b * S * ld + h * HE;
@@ -956,65 +985,77 @@ __global__ __launch_bounds__(64) void vg_attn_cls_bwd_kernel(const bf16* __restr
   const bf16* vb = qb + 2 * E;
   bf16* dqb = dqkv + (size_t)b * S * ld + h * HE;
   const float lse0 = lse_cls[(size_t)b * H + h];
-  bf16x8 q0[CPR], d0[CPR];
-  float delta = 0.f;  // sum_d dO_0[d] O_0[d], the same in every lane
-#pragma unroll
-  for (int c = 0; c < CPR; ++c) {
-    q0[c] = *(const bf16x8*)(qb + 8 * c);
-    d0[c] = *(const bf16x8*)(do_cls + (size_t)b * E + h * HE + 8 * c);
-    const bf16x8 o8 = *(const bf16x8*)(o_cls + (size_t)b * E + h * HE + 8 * c);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) delta = fmaf(vg_bf2f(d0[c][t]), vg_bf2f(o8[t]), delta);
+  float dpart = 0.f;  // delta = sum_d dO_0[d] O_0[d]
+  for (int d = lane; d < HE; d += 64) {
+    q0l[d] = vg_bf2f(qb[d]);
+    const float dv = vg_bf2f(do_cls[(size_t)b * E + h * HE + d]);
+    d0l[d] = dv;
+    dpart = fmaf(dv, vg_bf2f(o_cls[(size_t)b * E + h * HE + d]), dpart);
   }
+  const float delta = vg_wave_sum(dpart);
+  __syncthreads();
+  float qc[8], dc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { qc[t] = q0l[8 * (act ? c : 0) + t]; dc[t] = d0l[8 * (act ? c : 0) + t]; }
+  for (int r0 = 0; r0 < S; r0 += RPI) {
+    const int r = r0 + rr;
+    if (act && r < S) {
+      const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)r * ld + 8 * c);
+      const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)r * ld + 8 * c);
+      float a = 0.f, e = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { a = fmaf(qc[t], vg_bf2f(k8[t]), a); e = fmaf(dc[t], vg_bf2f(v8[t]), e); }
+      ps[r * CPR + c] = a;
+      pd[r * CPR + c] = e;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
     const int j = lane + 64 * rnd;
-    float dsv = 0.f;
+    float dsv = 0.f, pb = 0.f;
     if (j < S) {
       float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int c = 0; c < CPR; ++c) {
-        const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)j * ld + 8 * c);
-        const bf16x8 v8 = *(const bf16x8*)(vb + (size_t)j * ld + 8 * c);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          sc = fmaf(vg_bf2f(q0[c][t]), vg_bf2f(k8[t]), sc);
-          dp = fmaf(vg_bf2f(d0[c][t]), vg_bf2f(v8[t]), dp);
-        }
-      }
+      for (int cc = 0; cc < CPR; ++cc) { sc += ps[j * CPR + cc]; dp += pd[j * CPR + cc]; }
       const float p = __expf(sc * scale - lse0);
-      dsv = vg_bf2f(vg_f2bf(p * (dp - delta) * scale));  // bf16: an MFMA operand in the full kernel
-      const float pb = vg_bf2f(vg_f2bf(p));
-      // the key's rows of dK and dV: rank one in the CLS query
-      bf16* rowp = dqb + (size_t)j * ld;
-#pragma unroll
-      for (int c = 0; c < CPR; ++c) {
-        bf16x8 dk8, dv8;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { dk8[t] = vg_f2bf(dsv * vg_bf2f(q0[c][t])); dv8[t] = vg_f2bf(pb * vg_bf2f(d0[c][t])); }
-        *(bf16x8*)(rowp + E + 8 * c) = dk8;
-        *(bf16x8*)(rowp + 2 * E + 8 * c) = dv8;
-      }
+      dsv = vg_bf2f(vg_f2bf(p * (dp - delta) * scale));  // bf16: MFMA operands in the full kernel
+      pb = vg_bf2f(vg_f2bf(p));
     }
     dsl[j] = dsv;
+    pbl[j] = pb;
   }
   __syncthreads();
-  // dQ: row 0 = sum_j ds_j K_j, every other row zero
-  if (lane < HE / 2) {
-    float a0 = 0.f, a1 = 0.f;
-    for (int j = 0; j < S; ++j) {
-      const bf16x2 k2 = *(const bf16x2*)(kb + (size_t)j * ld + 2 * lane);
-      const float dj = dsl[j];
-      a0 = fmaf(dj, vg_bf2f(k2[0]), a0);
-      a1 = fmaf(dj, vg_bf2f(k2[1]), a1);
+  // dK_j = ds_j q0, dV_j = p_j dO_0 (rank one in the CLS query); dQ_0 = sum_j ds_j K_j
+  float qa[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) qa[t] = 0.f;
+  for (int r0 = 0; r0 < S; r0 += RPI) {
+    const int r = r0 + rr;
+    if (act && r < S) {
+      const bf16x8 k8 = *(const bf16x8*)(kb + (size_t)r * ld + 8 * c);
+      const float dj = dsl[r], pj = pbl[r];
+      bf16x8 dk8, dv8;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        dk8[t] = vg_f2bf(dj * qc[t]);
+        dv8[t] = vg_f2bf(pj * dc[t]);
+        qa[t] = fmaf(dj, vg_bf2f(k8[t]), qa[t]);
+      }
+      bf16* rowp = dqb + (size_t)r * ld + 8 * c;
+      *(bf16x8*)(rowp + E) = dk8;
+      *(bf16x8*)(rowp + 2 * E) = dv8;
+      if (r > 0) *(u32x4*)rowp = (u32x4){0u, 0u, 0u, 0u};  // dQ is zero off the CLS row
     }
-    bf16x2 dq2; dq2[0] = vg_f2bf(a0); dq2[1] = vg_f2bf(a1);
-    *(bf16x2*)(dqb + 2 * lane) = dq2;
   }
-  const u32x4 z = {0u, 0u, 0u, 0u};
-  for (int i = lane; i < (S - 1) * CPR; i += 64) {
-    const int r = 1 + i / CPR, c = i - (r - 1) * CPR;
-    *(u32x4*)(dqb + (size_t)r * ld + 8 * c) = z;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ps[lane * 8 + t] = qa[t];
+  __syncthreads();
+  for (int d = lane; d < HE; d += 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPI; ++q) a += ps[(q * CPR + (d >> 3)) * 8 + (d & 7)];
+    dqb[d] = vg_f2bf(a);
   }
 }
 
