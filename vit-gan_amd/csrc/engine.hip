@@ -346,15 +346,16 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     VG_TRY(vg_pack_rows_launch(pj, st));
   }
   auto row_fwd = [&](const bf16* A, int K, const bf16* Wp, const float* bias, const bf16* res, bf16* Y, bf16* Yn, float* mean,
-                     float* rstd, const float* gamma, const float* beta, int site) -> int {
+                     float* rstd, const float* gamma, const float* beta, int site, int rows = 0, int drm = 1, long long ldr = 0) -> int {
     VgRowArgs ra = {};
-    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = res; ra.Y = Y; ra.Yn = Yn;
-    ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = 1e-5f;
+    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.bias = bias; ra.res = res; ra.ldr = ldr; ra.Y = Y; ra.Yn = Yn;
+    ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = 1e-5f; ra.drop_row_mul = drm;
     if (dr.thr) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
     const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, st);
     return r > 0 ? 0 : (r < 0 ? -r : -3);
   };
 
+  bool tail_norm_done = false;  // the final LayerNorm already sits in the epilogue of the top block's fc2 (full-row tail)
   for (int l = 0; l < d.L; ++l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* x = w.X + (size_t)l * ME;
@@ -377,6 +378,17 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
     if (l == d.L - 1) {
       // Top block: only its CLS rows reach the classifier, so everything behind the attention runs on those B rows (compact tensors;
       // A = rows b S of `ao`, residual = rows b S of x by their leading dimension; dropout bits = those of rows b S of the full tensor)
+      if (rown && cls_attn && vg_row_nwg(B)) {
+        // the same full-row kernels as the blocks below, M = B: out-projection + residual + norm2, then fc2 + residual + the FINAL
+        // LayerNorm (its rows are exactly the CLS rows) - the tiled kernel covers so small a problem with 6-12 workgroups whose 12-24
+        // k-steps each wait out a full memory latency (22 us for the fc2 launch), the full-row kernel keeps two stages in flight
+        VG_TRY(row_fwd(w.t_ao, E, wp + po_wo, P + lo + lay.bo, x, w.t_xmid, w.t_xn2, w.t_mean2, w.t_rstd2, P + lo + lay.ln2_w, P + lo + lay.ln2_b,
+                       1 + 2 * l, B, S, (long long)S * E));  // residual = rows b S of x through its row stride
+        VG_TRY(lin_fwd(w.t_xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, w.t_a1, B, rE, VG_ACT_GELU, 0.f, nullptr, (bf16*)w.t_z1, nullptr, st, nullptr, 0, 2));
+        VG_TRY(row_fwd(w.t_a1, rE, wp + po_w2, P + lo + lay.b2, w.t_xmid, w.t_xtop, w.hcls, w.meanf, w.rstdf, P + lay.lnf_w, P + lay.lnf_b, 2 + 2 * l, B, S));
+        tail_norm_done = true;
+        continue;
+      }
       VgGemmProb po = cls_attn ? mk(w.t_ao, E, Pb + lo + lay.wo, E, B, E, E) : mk(ao, S * E, Pb + lo + lay.wo, E, B, E, E);
       po.C = w.t_xmid; po.ldc = E; po.bias = P + lo + lay.bo; po.res = x; po.ldr = S * E;
       set_drop(po, dr, 1 + 2 * l, 0); po.drop_row_mul = S;
@@ -412,7 +424,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
-  VG_TRY(vg_ln_fwd_launch(w.t_xtop, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  if (!tail_norm_done) VG_TRY(vg_ln_fwd_launch(w.t_xtop, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
   VG_TRY(lin_fwd(w.hcls, E, Pb + lay.hw1, P + lay.hb1, w.th, B, E, VG_ACT_TANH, 0.f, nullptr, nullptr, nullptr, st));
   VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
   return 0;
@@ -442,10 +454,10 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   const bool drop = dr.thr != 0;
   // dx = gres + LayerNorm'(A W) in one kernel (gemm_row.hip)
   auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma,
-                     const bf16* gres, bf16* dx, bf16* dxm, float* part, int site) -> int {
+                     const bf16* gres, bf16* dx, bf16* dxm, float* part, int site, int rows = 0, int drm = 1) -> int {
     VgRowArgs ra = {};
-    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
-    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = part;
+    ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
+    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = part; ra.drop_row_mul = drm;
     if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
     const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, st);
     return r > 0 ? 0 : (r < 0 ? -r : -3);
@@ -453,6 +465,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   VgCtx* ctx = (VgCtx*)net->ctx;
   hipStream_t sd = ctx ? ctx->side : st;  // stream of the weight-gradient side work
   const int top = d.L - 1;
+  const bool tail_row = rown && !net->attn_fp8 && vg_row_nwg(B) > 0;  // the top block's pruned tail on the full-row kernels (as the forward chose)
   VgFoldJobs folds; folds.n = 0;  // partial-sum folds queued by this call: one launch at its end
   if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
@@ -464,7 +477,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     if (head1) VG_TRY(vg_fold_push(folds, w.hpart, vg_head_bwd_parts(B), vg_head_bwd_part_width(E, d.Kc), G + lay.hw2, d.Kc * E, G + lay.hb1, E,
                                    G + lay.hb2, d.Kc, nullptr, 0));
     else VG_TRY(vg_colsum_bf16_launch(w.dzh, E, B, E, w.part_cs, G + lay.hb1, 1, st));
-    VgGemmProb p = wg(w.dzh, E, w.hcls, E, B, w.slab, (long long)E * E, 1);
+    // (a few K slices: with one, the three 128 x 384 tiles of this 384 x 384 x B problem are three workgroups walking 16 stages - 18 us at B = 512)
+    VgGemmProb p = wg(w.dzh, E, w.hcls, E, B, w.slab, (long long)E * E, B >= 512 ? 4 : (B >= 256 ? 2 : 1));
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
   }
@@ -580,9 +594,14 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       // attention backward (d ao) and the QKV input gradient's residual operand (d x_mid) need every row.
       const bf16* gb2c = drop ? w.t_gb2 : w.dxcls;
       VG_TRY(lin_dgrad(gb2c, Pb + lo + lay.w2, w.t_dz1, B, E, rE, VG_ACT_MUL_Z8, (const bf16*)w.t_z1, nullptr, 0.f, st));
-      VG_TRY(lin_dgrad(w.t_dz1, Pb + lo + lay.w1, w.t_dxn2, B, rE, E, 0, nullptr, nullptr, 0.f, st));
-      VG_TRY(vg_ln_bwd_launch(w.t_dxn2, w.t_xmid, w.t_mean2, w.t_rstd2, P + lo + lay.ln2_w, w.dxcls, w.t_dxmid, part2, B, E, drop ? w.t_gb1 : nullptr,
-                              dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st, 1, S));
+      if (tail_row) {  // fc1 input gradient + norm2 backward in the full-row kernel, M = B (the forward's twin: see there)
+        VG_TRY(row_bwd(w.t_dz1, rE, wp + po_w1T, w.t_xmid, w.t_mean2, w.t_rstd2, P + lo + lay.ln2_w, w.dxcls, w.t_dxmid, drop ? w.t_gb1 : nullptr, part2,
+                       1 + 2 * l, B, S));
+      } else {
+        VG_TRY(lin_dgrad(w.t_dz1, Pb + lo + lay.w1, w.t_dxn2, B, rE, E, 0, nullptr, nullptr, 0.f, st));
+        VG_TRY(vg_ln_bwd_launch(w.t_dxn2, w.t_xmid, w.t_mean2, w.t_rstd2, P + lo + lay.ln2_w, w.dxcls, w.t_dxmid, part2, B, E, drop ? w.t_gb1 : nullptr,
+                                dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st, 1, S));
+      }
       const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
       VG_TRY(lin_dgrad(gb1c, Pb + lo + lay.wo, w.t_dao, B, E, E, 0, nullptr, nullptr, 0.f, st));
       if (!net->attn_fp8) VG_TRY(vg_scatter_cls_launch(w.t_dxmid, cur.gmid, B, S, E, st));  // (d ao stays compact: the CLS-query attention backward below)
@@ -628,7 +647,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
-    VG_TRY(vg_fold_push(folds, part2, l == top ? vg_ln_bwd_nparts(B) : lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
+    VG_TRY(vg_fold_push(folds, part2, l == top ? (tail_row ? vg_row_nwg(B) : vg_ln_bwd_nparts(B)) : lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
     if (!pairing) VG_TRY(wgrad_blocks(l, 1));  // side-stream schedule: block by block, behind the block's input-gradient chain
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;

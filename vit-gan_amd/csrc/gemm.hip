@@ -596,7 +596,7 @@ int vg_gemm_launch(VgGemmProb* probs, int n, int mode, hipStream_t stream) {
 #endif
     // epilogues that fit the 128-register budget of 8-wave workgroups (sin / cos / tanh variants do not)
     const bool light = probs[i].act == VG_ACT_NONE || probs[i].act == VG_ACT_MUL_Z || probs[i].act == VG_ACT_MUL_Z8 || probs[i].act == VG_ACT_GELU;
-    if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;
+    if (t4 < t4min || mode == VG_TN || !light) wm4 = 0;  // (128-row tiles for the generator's mapping Linear - M = 256, 96 -> 192 workgroups - measured 23.5 vs 24.3 us: not kept)
   }
 #ifdef VG_TUNING
   static const int wm_env = getenv("VG_GEMM_WM") ? atoi(getenv("VG_GEMM_WM")) : 0;  // force the tile height

@@ -232,6 +232,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       constexpr int HM = 5, NH = (MT + HM - 1) / HM;
       const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
       const float dscale = a.drop_scale;
+      const unsigned drm = a.drop_row_mul > 1 ? (unsigned)a.drop_row_mul : 1u;
+      const size_t ldres = a.ldr > 0 ? (size_t)a.ldr : (size_t)RW_E;
       f32x4 b4[3];
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             dst[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-            if (e.res && !RW_DBG(32)) dst[i] = *(const bf16x8*)(e.res + row * RW_E + 8 * (sub + 16 * i));
+            if (e.res && !RW_DBG(32)) dst[i] = *(const bf16x8*)(e.res + row * ldres + 8 * (sub + 16 * i));
             if (SLN) wn[SLN ? i : 0] = *(const bf16x8*)(e.wmod + row * RW_E + 8 * (sub + 16 * i));
           }
         };
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
               const int n = 48 * wid + 16 * nt + 4 * g;
               f32x4 v = acc[nt][mt0 + mt < MT ? mt0 + mt : 0] + b4[nt];
               if (dthr) {
-                const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * (mt0 + mt) + li) * (unsigned)RW_E + (unsigned)n) >> 2);
+                const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * (mt0 + mt) + li) * drm * (unsigned)RW_E + (unsigned)n) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= vg_drop_factor(wd, r, dthr, dscale);
               }
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       const int subl = ln % LPR, rgl = ln / LPR;
       const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
       const float dscale = a.drop_scale;
+      const unsigned drm = a.drop_row_mul > 1 ? (unsigned)a.drop_row_mul : 1u;
       auto zero_chunk = [] { chunk_t z; for (int j = 0; j < CH; ++j) z[j] = (bf16)0.f; return z; };
       auto row_sum = [&](float v) { v = rw_row16_sum(v); if (LPR == 32) v += __shfl_xor(v, 16, 64); return v; };
       chunk_t xn[3];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
             for (int j = 0; j < CH; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), vg_bf2f(gr[i][j])));
             if (!RW_DBG(8)) *(chunk_t*)(e.dx + row * RW_E + c) = o;
             if (e.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
-              const unsigned i4 = ((unsigned)row * (unsigned)RW_E + (unsigned)c) >> 2;
+              const unsigned i4 = ((unsigned)row * drm * (unsigned)RW_E + (unsigned)c) >> 2;
 #pragma unroll
               for (int q = 0; q < CH / 4; ++q) {
                 const unsigned wd = vg_drop_word(dkey, i4 + q);
@@ -612,8 +615,8 @@ int vg_row_nwg(int M) {
 
 int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
   const int nwg = vg_row_nwg(a.M);
-  if (!nwg || a.K < 128 || (a.K & 63) || (a.lda & 7) || !a.A || !a.Wp) return 0;
-  if ((long long)a.M * RW_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
+  if (!nwg || a.K < 128 || (a.K & 63) || (a.lda & 7) || (a.ldr & 7) || !a.A || !a.Wp) return 0;
+  if ((long long)a.M * (a.drop_row_mul > 1 ? a.drop_row_mul : 1) * RW_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
   a.units = a.M / 16;
   a.nwg = nwg;
 #ifdef VG_TUNING

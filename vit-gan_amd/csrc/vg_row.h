@@ -16,6 +16,7 @@ struct VgRowArgs {
   // ---- VG_ROW_LNFWD:  y = res + drop(A W^T + bias);  yn = LN(y) * gamma + beta ------------------------------------
   const float* bias;       // [384] (nullable)
   const bf16* res;         // [M, 384] (nullable)
+  long long ldr;           // row stride of res in elements (0 = 384): e.g. S * 384 when the residual is the CLS rows of a [B*S, 384] tensor
   bf16* Y;                 // [M, 384]
   bf16* Yn;                // [M, 384] normalised rows; nullptr: no LayerNorm follows (Y only)
   float* mean_out; float* rstd_out;  // [M] statistics of Y (written when Yn)
@@ -40,6 +41,7 @@ struct VgRowArgs {
   // ---- both -------------------------------------------------------------------------------------------------------
   const float* gamma;      // [384]
   unsigned drop_thresh, drop_key; float drop_scale; const unsigned* drop_step;  // LNFWD: mask of drop(.); LNBWD: mask of dxm
+  int drop_row_mul;        // > 1: row m of this problem draws the mask bits of row m * drop_row_mul of a larger tensor (the CLS rows of [B*S, 384])
 };
 
 // number of workgroups (= rows of `part`) a problem of M rows is run with; 0 when the kernel does not take it
