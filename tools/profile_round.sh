@@ -25,4 +25,12 @@ python3 tools/pmc_summary.py $OUT/step_mfma $OUT/step_fetch $OUT/step_write $OUT
 for n in default roof; do f=$(find $OUT/ks_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_ks_$n.csv; done
 python3 tools/gemm_bench.py > $OUT/${TAG}_gemm_bench.txt 2>&1
 python3 tools/row_bench.py > $OUT/${TAG}_row_bench.txt 2>&1
-tail -4 $OUT/traffic.txt; tail -12 $OUT/summary.txt; grep -v amdgpu.ids $OUT/${TAG}_gemm_bench.txt
+# one step as a launch-by-launch timeline (from the kernel trace of the first run), the step with the gradient penalty, the vendor-GEMM calibration,
+# the stage-by-stage parity table and the bench line itself
+python3 tools/step_timeline.py $OUT/ks_default > $OUT/${TAG}_step_timeline.txt 2>&1
+(cd /tmp && prof ks_gp --kernel-trace --stats --output-format csv -d $OUT/ks_gp -- python3 $R/bench.py --loss wasserstein --gp 10 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline)
+f=$(find $OUT/ks_gp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_gp_step_kernel_stats.csv
+(python3 tools/micro/blas_cmp.py; python3 tools/gemm_bench.py) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_vendor_gemm_calibration_raw.txt
+python3 -m pytest tests/test_blocks_gpu.py -m gpu -q -s 2>&1 | grep -E "tensors checked|SLN scalars|^ +(sln|transformer_layers|layer_norm)" > $OUT/stage_raw.txt
+python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
+tail -4 $OUT/traffic.txt; tail -12 $OUT/summary.txt; grep -v amdgpu.ids $OUT/${TAG}_gemm_bench.txt; cut -c1-400 $OUT/${TAG}_bench_line.json
