@@ -247,6 +247,9 @@ def main():
                     help="1: fp8 (e4m3) MFMA operands for the attention's Q.K^T and P.V; -1 (default): on for --workload c5 (BASELINE.json "
                          "configs[4] names fp8 MFMA attention), off otherwise")
     ap.add_argument("--two-stream", type=int, default=0, help="1: run the step as two concurrent chains on two HIP streams (single GPU)")
+    ap.add_argument("--dense-top-block", type=int, default=0,
+                    help="1: compute every row of the top encoder block (the reference's operator graph row for row); default 0: only the CLS rows "
+                         "the classifier reads behind that block's attention - same logits and gradients (DESIGN.md s3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="profiling aid: skip the dominant-kernel timing leg, so a rocprofv3 run of this command contains the step's launches only")
@@ -318,7 +321,8 @@ def main():
     use_graph = True if args.graph < 0 else bool(args.graph)
     eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                     concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
-                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp)
+                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp,
+                    dense_top_block=bool(args.dense_top_block))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
@@ -362,7 +366,7 @@ def main():
         gd = G._dims
         f_g = gen_flops_per_image(gd.Z, gd.T, gd.E, gd.L, gd.O, gd.CW)
         f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image (the reference's operator graph)
-        f_exec = f_step - 8 * vit_dead_flops_per_image(IMG, geo["patch"], geo["embed"], fp8_attention=fp8_attn)  # what the engine really multiplies
+        f_exec = f_step - (0 if args.dense_top_block else 8 * vit_dead_flops_per_image(IMG, geo["patch"], geo["embed"], fp8_attention=fp8_attn))  # what the engine really multiplies
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
         # the roofline leg always times the C2 shape
@@ -390,8 +394,8 @@ def main():
                        "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1,
                        "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "flops_executed_per_image_step": f_exec,
-                       "pruned": "top encoder block behind its attention runs on the CLS rows only (the classifier reads nothing else, modules.py:195); "
-                                 "values and gradients unchanged",
+                       "pruned": None if args.dense_top_block else "top encoder block behind its attention runs on the CLS rows only (the classifier reads "
+                                 "nothing else, modules.py:195); values and gradients unchanged; --dense-top-block 1 computes every row",
                        "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
             "roofline": roof,
         }

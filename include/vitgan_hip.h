@@ -303,6 +303,10 @@ typedef struct VgVitNet {
   int attn_fp8;                 /* 1: fp8 (OCP e4m3) MFMA operands for the attention's activation products, Q.K^T (forward
                                    and the backward's recompute) and P.V, as BASELINE.json's 128x128 configuration asks;
                                    gradient-carrying products stay bf16.  0 = bf16 everywhere (default; parity tiers) */
+  int dense_top;                /* ABI v7.  0 (default): the top encoder block computes what the classifier reads - behind its attention
+                                   only the B CLS rows (modules.py:195 takes x[:, 0, :]; the other rows of its output are never read and their
+                                   gradient is exactly zero), forward, backward and weight gradients.  1: every row of it, like the blocks below -
+                                   the reference's operator graph row for row (for A/B measurements and the test that the two agree) */
 } VgVitNet;
 /* img: [B,C,IH,IH] fp32 (img_is_bf16 = 0) or bf16; logits fp32 [B,Kc].  ws keeps everything the
  * backward needs; one ws per in-flight forward. */

@@ -31,7 +31,7 @@ class VgVitLayout(C.Structure):
 class VgVitNet(C.Structure):
     _fields_ = [("d", VgVitDims), ("P", c_void_p), ("Pb", c_void_p), ("G", c_void_p),
                 ("dropout_p", c_float), ("dropout_seed", C.c_ulonglong), ("dropout_step", c_void_p), ("ctx", c_void_p),
-                ("attn_fp8", c_int)]
+                ("attn_fp8", c_int), ("dense_top", c_int)]
 
 
 class VgVitWsMap(C.Structure):

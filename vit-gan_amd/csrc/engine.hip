@@ -372,10 +372,11 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
       VG_TRY(vg_ln_fwd_launch(x, E, P + lo + lay.ln1_w, P + lo + lay.ln1_b, xn1, E, w.mean1 + (size_t)l * M,
                               w.rstd1 + (size_t)l * M, M, E, 1e-5f, st));
     VG_TRY(lin_fwd(xn1, E, Pb + lo + lay.wqkv, P + lo + lay.bqkv, qkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    const bool cls_attn = (l == d.L - 1) && !net->attn_fp8;  // top block: the CLS query is the only one the classifier sees
+    const bool tail = (l == d.L - 1) && !net->dense_top;       // top block: behind its attention only the CLS rows matter
+    const bool cls_attn = tail && !net->attn_fp8;              // ... and the CLS query is the only one the classifier sees
     if (cls_attn) VG_TRY(vg_attn_cls_fwd_launch(qkv, w.t_ao, w.t_lse, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
     else VG_TRY(vg_attn_fwd_launch(qkv, ao, w.lse + (size_t)l * B * d.H * S, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
-    if (l == d.L - 1) {
+    if (tail) {
       // Top block: only its CLS rows reach the classifier, so everything behind the attention runs on those B rows (compact tensors;
       // A = rows b S of `ao`, residual = rows b S of x by their leading dimension; dropout bits = those of rows b S of the full tensor)
       if (rown && cls_attn && vg_row_nwg(B)) {
@@ -424,7 +425,9 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   }
   // final LayerNorm acts on every row in the reference (:236) but only the CLS row feeds the
   // classifier (:195): normalise the B CLS rows only.
-  if (!tail_norm_done) VG_TRY(vg_ln_fwd_launch(w.t_xtop, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  // final LayerNorm: acts on every row in the reference (:236), only the CLS rows feed the classifier (:195)
+  if (net->dense_top) VG_TRY(vg_ln_fwd_launch(w.X + (size_t)d.L * ME, (long long)S * E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
+  else if (!tail_norm_done) VG_TRY(vg_ln_fwd_launch(w.t_xtop, E, P + lay.lnf_w, P + lay.lnf_b, w.hcls, E, w.meanf, w.rstdf, B, E, 1e-5f, st));
   VG_TRY(lin_fwd(w.hcls, E, Pb + lay.hw1, P + lay.hb1, w.th, B, E, VG_ACT_TANH, 0.f, nullptr, nullptr, nullptr, st));
   VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
   return 0;
@@ -465,7 +468,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   VgCtx* ctx = (VgCtx*)net->ctx;
   hipStream_t sd = ctx ? ctx->side : st;  // stream of the weight-gradient side work
   const int top = d.L - 1;
-  const bool tail_row = rown && !net->attn_fp8 && vg_row_nwg(B) > 0;  // the top block's pruned tail on the full-row kernels (as the forward chose)
+  const bool tail = !net->dense_top;                                          // the top block's pruned tail (as the forward chose)
+  const bool tail_row = tail && rown && !net->attn_fp8 && vg_row_nwg(B) > 0;  // ... on the full-row kernels
   VgFoldJobs folds; folds.n = 0;  // partial-sum folds queued by this call: one launch at its end
   if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
@@ -483,9 +487,15 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
   }
   VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));
-  // dL/dX[L] on the CLS rows (it is zero elsewhere) and its masked copy for the top block's MLP dropout - the bits of rows b S of the full tensor
-  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.t_xtop, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, drop ? w.t_gb2 : nullptr, dr.thr,
-                          site_key(dr, 2 + 2 * top), dr.scale, dr.step, st, 1, S));
+  if (tail) {
+    // dL/dX[L] on the CLS rows (it is zero elsewhere) and its masked copy for the top block's MLP dropout - the bits of rows b S of the full tensor
+    VG_TRY(vg_ln_bwd_launch(w.dhcls, w.t_xtop, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, drop ? w.t_gb2 : nullptr, dr.thr,
+                            site_key(dr, 2 + 2 * top), dr.scale, dr.step, st, 1, S));
+  } else {
+    VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)d.L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
+    // dL/dX[L]: the CLS rows, zero elsewhere - and its masked copy for the last block's MLP dropout, in the same launch
+    VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st, drop ? w.set[top & 1].gm2 : nullptr, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step));
+  }
   if (want_wgrad)  // (the final LayerNorm's own partial count: B rows, standalone kernel; w.part is nobody else's)
     VG_TRY(vg_fold_push(folds, w.part, vg_ln_bwd_nparts(B), 3 * E, G + lay.lnf_w, E, G + lay.lnf_b, E, nullptr, E, nullptr, 0));
   }
@@ -527,16 +537,18 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VgGemmProb* q = pr + np;
       q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, splits);
       q[0].colsum = bs; q[0].colsum_split_stride = BW;
-      if (lb == top) { np += 1; continue; }  // top block: the other three are sums over its B CLS rows (below)
+      if (tail && lb == top) { np += 1; continue; }  // top block: the other three are sums over its B CLS rows (below)
       q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, splits);
       q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, splits);
       q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, splits);
       q[2].colsum = bs + 3 * E; q[2].colsum_split_stride = BW;
+      if (lb == top) { q[3].colsum = bs + 3 * E + rE; q[3].colsum_split_stride = BW; }  // (dense top block: fc2's bias rides along here)
       np += 4;
     }
     VG_TRY(vg_gemm_launch(pr, np, VG_TN, sd));
     const int ns = pr[0].splits;  // (the launcher drops empty slices; every problem here has the same M rows)
-    if (nb == 2 && la != top) {  // both blocks' K slices in one launch
+    const bool ptop = tail && la == top;  // this launch holds the pruned top block: its slab has the QKV part only
+    if (nb == 2 && !ptop) {  // both blocks' K slices in one launch
       const long long lo0 = lay.layer0 + (long long)la * lay.layer_stride, lo1 = lo0 - lay.layer_stride;
       VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, ns, G + lo0, G + lo1,
                                     lay.layer_weights, 1, sd));
@@ -545,10 +557,12 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       const int lb = la - j;
       const long long lob = lay.layer0 + (long long)lb * lay.layer_stride;
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
-      if (nb == 1 || la == top)  // (the top block's slab holds its QKV part only: wqkv is the first region of a layer)
-        VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, ns, G + lob, lb == top ? 3LL * E * E : lay.layer_weights, 1, sd));
-      VG_TRY(vg_fold_push(folds, bs, ns, (int)BW, G + lob + lay.bqkv, 3 * E, lb == top ? nullptr : G + lob + lay.b1, rE, nullptr, E, nullptr, 0));
-      if (lb != top) continue;
+      const bool pt = tail && lb == top;
+      if (nb == 1 || ptop)  // (the pruned top block's slab holds its QKV part only: wqkv is the first region of a layer)
+        VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, ns, G + lob, pt ? 3LL * E * E : lay.layer_weights, 1, sd));
+      VG_TRY(vg_fold_push(folds, bs, ns, (int)BW, G + lob + lay.bqkv, 3 * E, pt ? nullptr : G + lob + lay.b1, rE, (lb == top && !pt) ? G + lob + lay.b2 : nullptr, E,
+                          nullptr, 0));
+      if (!pt) continue;
       // ---- top block: out-projection / fc1 / fc2 weight gradients as sums over the B CLS rows (every other row of their dY is exactly
       // zero), ONE K slice accumulated straight into the gradient buffer; b1 / b2 ride along as one partial row ----
       const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
@@ -588,7 +602,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* gb2 = drop ? cur.gm2 : cur.gin;   // gradient w.r.t. the fc2 output (before dropout2)
     // ---------------- input-gradient chain (main stream) ----------------
     const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
-    if (l == top) {
+    if (l == top && tail) {
       // Top block, pruned tail: dL/dX[L] lives on the B CLS rows only (w.dxcls; masked copy w.t_gb2), so the MLP half and the
       // out-projection run on compact [B, .] tensors; their results go back into zero-filled full-size tensors where the
       // attention backward (d ao) and the QKV input gradient's residual operand (d x_mid) need every row.
@@ -620,7 +634,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     }
-    if (l == top && !net->attn_fp8)
+    if (l == top && tail && !net->attn_fp8)
       VG_TRY(vg_attn_cls_bwd_launch(qkv, w.t_ao, w.t_dao, w.t_lse, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
     else
       VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
@@ -647,7 +661,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_CHECK_HIP(hipEventRecord(ctx->ev_main[l], st));
       VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[l], 0));
     }
-    VG_TRY(vg_fold_push(folds, part2, l == top ? (tail_row ? vg_row_nwg(B) : vg_ln_bwd_nparts(B)) : lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
+    VG_TRY(vg_fold_push(folds, part2, (l == top && tail) ? (tail_row ? vg_row_nwg(B) : vg_ln_bwd_nparts(B)) : lnparts, 3 * E, G + lo + lay.ln2_w, E, G + lo + lay.ln2_b, E, G + lo + lay.bo, E, nullptr, 0));
     if (!pairing) VG_TRY(wgrad_blocks(l, 1));  // side-stream schedule: block by block, behind the block's input-gradient chain
     {
       float* b2_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.b2 : nullptr;

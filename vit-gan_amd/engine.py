@@ -44,7 +44,7 @@ class GanEngine:
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
                  two_stream: bool = False, compress_mapping_grad: bool = False, gp_weight: float = 0.0,
-                 exchange_single_rank: bool = False):
+                 exchange_single_rank: bool = False, dense_top_block: bool = False):
         """concurrent_wgrad: the discriminator's weight gradients on a side stream beside its input gradients.  Off by default
         since the persistent GEMMs (csrc/gemm_wr.hip, gemm_tn.hip: their workgroups hold the CUs for a whole launch) - the
         side stream measured 6.70 against 6.67 ms/step.
@@ -71,6 +71,10 @@ class GanEngine:
         the exact fp32 all-reduce and a caller that wants the halved link traffic opts in (bench.py does and says so in its line).
         exchange_single_rank: run the staged backward and its all-reduces on a one-rank group as well (tests: the RCCL
         collectives inside a captured step, on a box with one GPU).
+        dense_top_block: compute EVERY row of the top encoder block like the reference's operator graph does.  Default off: behind
+        its attention that block runs on the B CLS rows only - the classifier reads nothing else (modules.py:195) and the gradient of the
+        other rows is exactly zero - with the same logits and gradients (tests/test_engine_gpu.py compares the two); the switch exists
+        for A/B measurements (``bench.py --dense-top-block 1``).
         use_graph: replay the step as one hipGraph.  On more than one rank the capture includes the RCCL all-reduces (backend
         "nccl"); when the capture is not possible (gloo process group, a torch build that cannot capture the collective) the
         engine says so loudly (warning + ``graph_fallback_reason``) and runs eager - it never falls back silently.
@@ -96,6 +100,7 @@ class GanEngine:
         self.clip_d, self.clip_g = clip_d, clip_g
         self.dp_chunks = 3  # pieces of the D / G backward whose gradient exchange overlaps the remaining backward
         self.compress_map = bool(compress_mapping_grad)
+        self.dense_top = int(bool(dense_top_block))
         self.gp_w = float(gp_weight)
         self.gp_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.gp_epsilon: Optional[torch.Tensor] = None  # tests: a fixed epsilon [B,1,1,1] instead of torch.rand
@@ -204,7 +209,7 @@ class GanEngine:
         step_ptr = self.step_t.data_ptr()
         mk = lambda i, g=None, ctx=True: _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(),  # noqa: E731
                                                        (fd.grad if g is None else g).data_ptr(), self.p_d, self.seed * 8 + i, step_ptr,
-                                                       self.ctx if ctx else None, int(self.vit.attention_fp8))
+                                                       self.ctx if ctx else None, int(self.vit.attention_fp8), self.dense_top)
         if self.two_stream:  # chains run side by side: no third stream inside a pass; the fake chain accumulates into grad2
             return (mk(0, ctx=False), mk(1, self.grad2, ctx=False), mk(2, ctx=False), mk(3, ctx=False)), self._gen_net(step_ptr)
         return (mk(0), mk(1), mk(2)), self._gen_net(step_ptr)
