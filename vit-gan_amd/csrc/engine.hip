@@ -460,7 +460,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
                      const bf16* gres, bf16* dx, bf16* dxm, float* part, int site, int rows = 0, int drm = 1) -> int {
     VgRowArgs ra = {};
     ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
-    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = part; ra.drop_row_mul = drm;
+    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = want_wgrad ? part : nullptr; ra.drop_row_mul = drm;  // (no parameter gradients wanted: no column sums)
     if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
     const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, st);
     return r > 0 ? 0 : (r < 0 ? -r : -3);

@@ -392,6 +392,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         for (int j = 0; j < CH; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
       const unsigned char* gam_lds = smem + RW_BODY;
       float s_gs = 0.f, s_bs = 0.f;  // SLN: d gs = sum dy w (xhat gamma + lbias), d bs = sum dy w
+      // part == nullptr: a pass that wants the input gradient only (the generator's pass through D) - no column sums, no fold
+      const bool sums = SLN || a.part != nullptr;
       auto ld_f32 = [&](const unsigned char* base, int i, float (&dst)[CH]) {
 #pragma unroll
         for (int q = 0; q < CH / 4; ++q) {
@@ -446,8 +448,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
                 d = dwm * g_s;
               }
               xh[i][j] = h;
-              ag[i][j] = fmaf(d, h, ag[i][j]);
-              ab[i][j] += d;
+              if (sums) { ag[i][j] = fmaf(d, h, ag[i][j]); ab[i][j] += d; }
               const float gv = d * gm[j];
               gg[i][j] = gv;
               c1 += gv;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
               if (!RW_DBG(8)) *(chunk_t*)(e.dxm + row * RW_E + c) = o;
             }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) ac[i][j] += vg_bf2f(o[j]);
+            for (int j = 0; j < CH; ++j) if (sums) ac[i][j] += vg_bf2f(o[j]);
           }
         }
       }
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       __syncthreads();  // the tile has been read
       float* red = (float*)smem;  // [3][NSL][384] (+ 16 scalars)
       constexpr int NSL = 8 * RPW;
-      {
+      if (sums) {
         const int slot = RPW * wid + rgl;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = tid + 512 * k;
-        if (c < 3 * RW_E) {
+        if (sums && c < 3 * RW_E) {
           const int which = c / RW_E, col = c - which * RW_E;
           const float* r0 = red + (which * NSL) * RW_E + col;
           float t8[8];
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     }
     n -= mt; m0 += 16 * mt; first = false;
   }
-  if (EPI == VG_ROW_LNBWD) {
+  if (EPI == VG_ROW_LNBWD && a.part) {
     float* out = a.part + (size_t)blockIdx.x * a.part_w;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -631,7 +632,7 @@ int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
     if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, true>), dim3(nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, false>), dim3(nwg), dim3(512), 0, st, a);
   } else if (epi == VG_ROW_LNBWD) {
-    if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || !a.part || (sln && (!a.lbias || !a.dw_acc))) return -1;
+    if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || (sln && (!a.part || !a.lbias || !a.dw_acc))) return -1;  // part == nullptr: no column sums (input gradient only)
     a.part_w = 3 * RW_E + (sln ? 64 : 0);
     if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, true>), dim3(nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, false>), dim3(nwg), dim3(512), 0, st, a);

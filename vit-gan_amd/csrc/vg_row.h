@@ -27,7 +27,8 @@ struct VgRowArgs {
   const float* mean; const float* rstd;  // [M]
   const bf16* gres;        // [M, 384] gradient arriving over the residual connection (nullable)
   bf16* dx; bf16* dxm;     // [M, 384]; dxm nullable
-  float* part;             // [nwg][3*384]: per workgroup column sums  d gamma | d beta | colsum(dxm ? dxm : dx)
+  float* part;             // [nwg][3*384]: per workgroup column sums  d gamma | d beta | colsum(dxm ? dxm : dx); nullptr (plain LayerNorm
+                           // only): no sums at all - a backward that wants the input gradient alone (the generator's pass through D)
   // ---- self-modulated LayerNorm (v1 generator, src/v1/spectral_layer_norm.py:19-20): wmod != nullptr -------------------------
   //      forward:  yn = w * (gs * (LN(y) * gamma + beta) + bs);   backward: dy_eff = dy * w * gs feeds the LayerNorm backward,
   //      dw_acc (+)= dy * (gs * (xhat * gamma + lbias) + bs), and the partial row gets d gs, d bs at [3*384], [3*384 + 1]
