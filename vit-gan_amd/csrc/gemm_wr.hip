@@ -330,6 +330,10 @@ __global__ __launch_bounds__(256, 2) void vg_gemm_wr_kernel(const VgWrArgs args)
           for (int r = 0; r < 8; ++r) o[r] = vg_f2bf(v[r]);
           *(bf16x8*)(eC2 + (unsigned)(m * eldc2 + ncol)) = o;
         }
+        if (ACT == VG_ACT_TANH) {  // the classifier's fc1 (modules.py:196-197)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = vg_tanh(v[r]);
+        }
         if (Z8) {
           union { bf16x8 b; u32x4 u; } cv; cv.b = pre[qq];
 #pragma unroll
@@ -403,6 +407,8 @@ int vg_gemm_wr_try(const VgGemmProb& p, int mode, hipStream_t stream) {
       else return 0;
     } else if (p.act == VG_ACT_GELU && feat == WF_C2) {
       WR_LAUNCH(0, VG_ACT_GELU, WF_C2);
+    } else if (p.act == VG_ACT_TANH && feat == 0) {  // classifier fc1 at M = B >= 256: 16 us on the tiled kernel's 12 workgroups
+      WR_LAUNCH(0, VG_ACT_TANH, 0);
     } else {
       return 0;
     }
