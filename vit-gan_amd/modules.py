@@ -291,6 +291,10 @@ class VisionTransformer(nn.Module):
             w = torch.cat((a.queries.weight, a.keys.weight, a.values.weight), dim=0)
             b = torch.cat((a.queries.bias, a.keys.bias, a.values.bias), dim=0)
             ctx = ops2.attention(ops2.linear(n1, w, b, slot(o_qkv)), a.n_attention_heads, 1.0 / float(a.head_embed_dim) ** 0.5)
+            if i == len(self.encoder) - 1:
+                # top block: the classifier reads the CLS row only (:195), so behind the attention the row-local operators - and with
+                # them their backward and double backward - run on the B CLS rows (the fused engine does the same, csrc/engine.hip)
+                ctx, h = ctx[:, :1, :], h[:, :1, :]
             h = h + blk.dropout1(ops2.linear(ctx, a.out_projection.weight, a.out_projection.bias, slot(o_wo)))
             n2 = ops2.layer_norm(h, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             z = ops2.act(ops2.linear(n2, blk.fc1.weight, blk.fc1.bias, slot(o_w1)), "gelu")
