@@ -211,7 +211,7 @@ static int pick_splits384(long long tiles, int Krows, int cap) {
 // =============================================================================================
 //                                   ViT (discriminator)
 // =============================================================================================
-#define VIT_SPLIT_CAP 12
+#define VIT_SPLIT_CAP 16
 #define EMB_SPLIT_CAP 32
 struct VitWs {
   bf16 *Apatch, *X, *xn1, *qkv, *ao, *xmid, *xn2, *a1, *xcls, *hcls, *th;
@@ -522,12 +522,27 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     static const int split_env = getenv("VG_VIT_SPLITS") ? atoi(getenv("VG_VIT_SPLITS")) : 0;
     if (split_env > 0 && split_env <= VIT_SPLIT_CAP / 2) splits = split_env;
 #endif
+    // K slices per BLOCK, the same in every schedule (so every schedule adds the same slices in the same order).  With the pruned tail the
+    // top block contributes its QKV problem only: the launch that holds it and the block below is 33 tiles instead of 48, and at 5 slices
+    // 165 workgroups on 256 CUs - those two blocks therefore take 7 slices (231 workgroups; 149 -> ~110 us), wherever they are launched.
+    int splits_top = splits;
+    if (tail && top >= 1) {
+      if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
+        splits_top = pick_splits384(tiles_wide(3 * E, E, bn) + (tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn)), M,
+                                    VIT_SPLIT_CAP / 2);
+      else
+        splits_top = pick_splits(tiles128(3 * E, E) + tiles, M, VIT_SPLIT_CAP / 2);
+    }
+    auto splits_of = [&](int lb) { return (tail && top >= 1 && (lb == top || lb == top - 1)) ? splits_top : splits; };
     VgGemmProb pr[8];
-    int np = 0;
+    int np = 0, first[2] = {0, 0};
+    long long slab_off[2] = {0, 0};
     for (int j = 0; j < nb; ++j) {
       const int lb = la - j;
+      const int sp = splits_of(lb);
+      if (j + 1 < nb) slab_off[j + 1] = slab_off[j] + (long long)sp * lay.layer_weights;
       VitWs::Set& sb = w.set[lb & 1];
-      float* slab = w.slab + (size_t)j * splits * lay.layer_weights;
+      float* slab = w.slab + slab_off[j];
       const bf16* gb1b = drop ? sb.gm1 : sb.gmid;
       const bf16* gb2b = drop ? sb.gm2 : sb.gin;
       // bias gradients = column sums of the same dY operands: they ride along in the GEMM (ones x A on the MFMA pipe),
@@ -535,31 +550,32 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       // here (lower blocks get it from the LN1 partials of the block above).
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
       VgGemmProb* q = pr + np;
-      q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, splits);
+      first[j] = np;
+      q[0] = wg(sb.dqkv, 3 * E, w.xn1 + (size_t)lb * ME, E, M, slab + lay.wqkv, lay.layer_weights, sp);
       q[0].colsum = bs; q[0].colsum_split_stride = BW;
       if (tail && lb == top) { np += 1; continue; }  // top block: the other three are sums over its B CLS rows (below)
-      q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, splits);
-      q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, splits);
-      q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, splits);
+      q[1] = wg(gb1b, E, w.ao + (size_t)lb * ME, E, M, slab + lay.wo, lay.layer_weights, sp);
+      q[2] = wg(sb.dz1, rE, w.xn2 + (size_t)lb * ME, E, M, slab + lay.w1, lay.layer_weights, sp);
+      q[3] = wg(gb2b, E, w.a1 + (size_t)lb * M * rE, rE, M, slab + lay.w2, lay.layer_weights, sp);
       q[2].colsum = bs + 3 * E; q[2].colsum_split_stride = BW;
       if (lb == top) { q[3].colsum = bs + 3 * E + rE; q[3].colsum_split_stride = BW; }  // (dense top block: fc2's bias rides along here)
       np += 4;
     }
     VG_TRY(vg_gemm_launch(pr, np, VG_TN, sd));
-    const int ns = pr[0].splits;  // (the launcher drops empty slices; every problem here has the same M rows)
     const bool ptop = tail && la == top;  // this launch holds the pruned top block: its slab has the QKV part only
-    if (nb == 2 && !ptop) {  // both blocks' K slices in one launch
+    if (nb == 2 && !ptop && pr[first[0]].splits == pr[first[1]].splits) {  // both blocks' K slices in one launch
       const long long lo0 = lay.layer0 + (long long)la * lay.layer_stride, lo1 = lo0 - lay.layer_stride;
-      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, ns, G + lo0, G + lo1,
+      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + slab_off[1], lay.layer_weights, pr[first[0]].splits, G + lo0, G + lo1,
                                     lay.layer_weights, 1, sd));
     }
     for (int j = 0; j < nb; ++j) {
       const int lb = la - j;
       const long long lob = lay.layer0 + (long long)lb * lay.layer_stride;
       float* bs = w.bslab + (size_t)lb * VIT_SPLIT_CAP * BW;
+      const int ns = pr[first[j]].splits;  // (the launcher drops empty slices; every problem of a block has the same M rows)
       const bool pt = tail && lb == top;
-      if (nb == 1 || ptop)  // (the pruned top block's slab holds its QKV part only: wqkv is the first region of a layer)
-        VG_TRY(vg_slab_reduce_launch(w.slab + (size_t)j * splits * lay.layer_weights, lay.layer_weights, ns, G + lob, pt ? 3LL * E * E : lay.layer_weights, 1, sd));
+      if (nb == 1 || ptop || pr[first[0]].splits != pr[first[nb - 1]].splits)  // (the pruned top block's slab holds its QKV part only: wqkv is the first region of a layer)
+        VG_TRY(vg_slab_reduce_launch(w.slab + slab_off[j], lay.layer_weights, ns, G + lob, pt ? 3LL * E * E : lay.layer_weights, 1, sd));
       VG_TRY(vg_fold_push(folds, bs, ns, (int)BW, G + lob + lay.bqkv, 3 * E, pt ? nullptr : G + lob + lay.b1, rE, (lb == top && !pt) ? G + lob + lay.b2 : nullptr, E,
                           nullptr, 0));
       if (!pt) continue;
@@ -567,7 +583,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       // zero), ONE K slice accumulated straight into the gradient buffer; b1 / b2 ride along as one partial row ----
       const bf16* gb1c = drop ? w.t_gb1 : w.t_dxmid;
       const bf16* gb2c = drop ? w.t_gb2 : w.dxcls;
-      float* bsc = bs + (size_t)(VIT_SPLIT_CAP - 1) * BW;  // the last row of the block's carve: the grouped launch above never has 12 slices
+      float* bsc = bs + (size_t)(VIT_SPLIT_CAP - 1) * BW;  // the last row of the block's carve: a block never has more than VIT_SPLIT_CAP / 2 slices
       VgGemmProb c[3];
       if (!net->attn_fp8) c[0] = wg(gb1c, E, w.t_ao, E, B, G + lob + lay.wo, 0, 1);  // the CLS query's attention output
       else { c[0] = wg(gb1c, E, w.ao + (size_t)lb * ME, E, B, G + lob + lay.wo, 0, 1); c[0].ldb = S * E; }  // rows b S of the full one
