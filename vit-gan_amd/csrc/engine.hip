@@ -733,6 +733,7 @@ struct GenWs {
   bf16 *y2, *dy2;  // patch-grid variant only: token rows [R, CW] before the un-patchify / after the patchify of d_img
   float *dw_acc, *part, *part_cs, *part_cs2, *emb_sum, *slab;
   bf16* wpack;  // E = 384: stage images of Wo | Wm | Wqkv^T | Wm^T per block, then s1_w^T, for the full-row GEMMs (gemm_row.hip)
+  bf16 *pdqkv, *pgm1, *pgm2;  // per-block copies of the weight-gradient dY operands (dropout on): two blocks' weight gradients go out as one launch
 };
 // generator rows R = B*T: the full-row kernels (SLN in the epilogue) take the Linears whose output is the embedding when E = 384
 static inline int gen_row_nwg(const VgGenDims& d, int R) { return (d.E == VG_ROW_N && d.O % 64 == 0 && d.O >= 128) ? vg_row_nwg(R) : 0; }
@@ -768,6 +769,7 @@ static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   w.y2 = c.take<bf16>(d.patch > 0 ? R * d.CW : 0);
   w.dy2 = c.take<bf16>(d.patch > 0 ? R * d.CW : 0);
   w.dw_acc = c.take<float>(R * E);
+  w.pdqkv = c.take<bf16>(L * R * 3 * E); w.pgm1 = c.take<bf16>(L * R * E); w.pgm2 = c.take<bf16>(L * R * E);
   w.part = c.take<float>((2 * L + 1) * (long long)vg_ln_bwd_nparts((int)R) * (3 * E + 64));  // one block per SLN backward
   w.part_cs = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * (d.O > 3 * E ? d.O : 3 * E));
   w.part_cs2 = c.take<float>((long long)vg_colsum_bf16_nparts((int)R) * d.CW);
@@ -917,8 +919,13 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
   VgFoldJobs folds; folds.n = 0;
   const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
   const bool drop = dr.thr != 0;
-  bf16* const gm2buf = w.gm[0];  // g masked for the MLP-branch dropout it meets next
-  bf16* const gm1buf = w.gm[1];  // gmid masked for the attention-branch dropout
+  // g masked for the MLP-branch dropout it meets next / gmid masked for the attention-branch dropout: one copy PER BLOCK (with the block's
+  // dqkv), so that the weight gradients of two blocks - which read them - can wait for each other and go out as ONE grouped launch
+  // (half the launches, folds and slab traffic; the discriminator's pairs, second half of round 3).  Without dropout the unmasked
+  // rotating buffers are the operands and every block launches its own.
+  auto gm2_of = [&](int l) { return drop ? w.pgm2 + (size_t)l * R * E : w.gm[0]; };
+  auto gm1_of = [&](int l) { return drop ? w.pgm1 + (size_t)l * R * E : w.gm[1]; };
+  auto dqkv_of = [&](int l) { return drop ? w.pdqkv + (size_t)l * R * 3 * E : w.dqkv; };
 
   // dh = gres + SLN'(A W) in one kernel
   auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* hx, int hbc, const float* mean, const float* rstd, const float* lw,
@@ -961,17 +968,39 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   if (rown) {  // first SIREN layer's input gradient + the final SLN's backward
     VG_TRY(row_bwd(w.dz1, d.O, w.wpack + (long long)d.L * pb, hL, 0, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, nullptr, g,
-                   drop ? gm2buf : nullptr, 0, w.part + (size_t)(2 * d.L) * part_sz, 101 + 2 * (d.L - 1)));
+                   drop ? gm2_of(d.L - 1) : nullptr, 0, w.part + (size_t)(2 * d.L) * part_sz, 101 + 2 * (d.L - 1)));
   } else {
     VG_TRY(lin_dgrad(w.dz1, Pb + lay.s1_w, w.ds, R, d.O, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_sln_bwd_launch(w.ds, hL, 0, w.wmod, w.meanf, w.rstdf, P + lay.slnf_w, P + lay.slnf_b, P + lay.slnf_s, P + lay.slnf_s + 1,
-                             nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
+                             nullptr, g, w.dw_acc, 0, w.part + (size_t)(2 * d.L) * part_sz, R, E, drop ? gm2_of(d.L - 1) : nullptr, dr.thr, site_key(dr, 101 + 2 * (d.L - 1)), dr.scale, dr.step, st));
   }
   {
     const long long lo = lay.layer0 + (long long)(d.L - 1) * lay.layer_stride;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * d.L) * part_sz, parts, PW, G + lay.slnf_w, E, G + lay.slnf_b, E, G + lo + lay.bm, E, G + lay.slnf_s, 2));
   }
   }  // stage 0
+  int pend[2], npend = 0;
+  auto gen_wgrad = [&](int la, int nb) -> int {  // blocks la, la - 1 (nb = 2) or la alone: grouped split-K launch + fold
+    int splits = pick_splits(2 * (tiles128(3 * E, E) + 2 * tiles128(E, E)), R, GEN_SPLIT_CAP / 2);
+    if (const int bn = wide_bn(E, E); bn && R % 32 == 0 && E % 128 == 0)
+      splits = pick_splits384(2 * (tiles_wide(3 * E, E, bn) + 2 * tiles_wide(E, E, bn)), R, GEN_SPLIT_CAP / 2);
+    VgGemmProb pr[6];
+    for (int j = 0; j < nb; ++j) {
+      const int lb = la - j;
+      float* slab = w.slab + (size_t)j * splits * lay.layer_weights;
+      pr[3 * j + 0] = wg(dqkv_of(lb), 3 * E, w.s1 + (size_t)lb * RE, E, R, slab + lay.wqkv, lay.layer_weights, splits);
+      pr[3 * j + 1] = wg(gm1_of(lb), E, w.cat + (size_t)lb * RE, E, R, slab + lay.wo, lay.layer_weights, splits);
+      pr[3 * j + 2] = wg(gm2_of(lb), E, w.s2 + (size_t)lb * RE, E, R, slab + lay.wm, lay.layer_weights, splits);
+    }
+    VG_TRY(vg_gemm_launch(pr, 3 * nb, VG_TN, st));
+    const long long lo0 = lay.layer0 + (long long)la * lay.layer_stride;
+    if (nb == 2)
+      VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)splits * lay.layer_weights, lay.layer_weights, pr[0].splits, G + lo0, G + lo0 - lay.layer_stride,
+                                    lay.layer_weights, 1, st));
+    else
+      VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo0, lay.layer_weights, 1, st));
+    return 0;
+  };
   for (int l = d.L - 1; l >= 0; --l) {
     const int stage = d.L - l;
     if (stage >= stage_end) break;
@@ -985,6 +1014,9 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     const bf16* htmp = w.htmp + (size_t)l * RE;
     const bf16* s2 = w.s2 + (size_t)l * RE;
     // hout = drop(mlp(s2)) + htmp  (transformer.py:87; MLP is a single Linear, muilti_layer_perceptron.py:37-42)
+    bf16* const gm2buf = gm2_of(l);
+    bf16* const gm1buf = gm1_of(l);
+    bf16* const dqkv_l = dqkv_of(l);
     const bf16* gb2 = drop ? gm2buf : g;
     const bf16* wp = w.wpack + (size_t)l * pb;
     if (rown) {  // block MLP input gradient + SLN2 backward + the residual-stream gradient
@@ -1000,32 +1032,36 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l) * part_sz, parts, PW, G + lo + lay.sln2_w, E, G + lo + lay.sln2_b, E, G + lo + lay.bo, E,
                  G + lo + lay.sln2_s, 2));
     VG_TRY(lin_dgrad(gb1, Pb + lo + lay.wo, w.dcat, R, E, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, w.dqkv, B, d.H, T, HE, scale, 0, st));
-    if (!rown) VG_TRY(lin_dgrad(w.dqkv, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
-    {
+    VG_TRY(vg_attn_bwd_launch(qkv, cat, w.dcat, w.lse + (size_t)l * B * d.H * T, dqkv_l, B, d.H, T, HE, scale, 0, st));
+    if (!rown) VG_TRY(lin_dgrad(dqkv_l, Pb + lo + lay.wqkv, w.ds, R, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    if (!drop) {  // the operands are the rotating buffers: this block's weight gradients now
       const long long tiles = tiles128(3 * E, E) + 2 * tiles128(E, E);
       int splits = pick_splits(tiles, R, GEN_SPLIT_CAP);
       if (const int bn = wide_bn(E, E); bn && R % 32 == 0 && E % 128 == 0)
         splits = pick_splits384(tiles_wide(3 * E, E, bn) + 2 * tiles_wide(E, E, bn), R, GEN_SPLIT_CAP);
       VgGemmProb pr[3];
-      pr[0] = wg(w.dqkv, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
+      pr[0] = wg(dqkv_l, 3 * E, s1, E, R, w.slab + lay.wqkv, lay.layer_weights, splits);
       pr[1] = wg(gb1, E, cat, E, R, w.slab + lay.wo, lay.layer_weights, splits);
       pr[2] = wg(gb2, E, s2, E, R, w.slab + lay.wm, lay.layer_weights, splits);
       VG_TRY(vg_gemm_launch(pr, 3, VG_TN, st));
       VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+    } else {  // per-block operands: two blocks per launch (the odd one out of a call goes alone, with the SAME K partition: every schedule adds the same slices)
+      pend[npend++] = l;
+      if (npend == 2) { VG_TRY(gen_wgrad(pend[0], 2)); npend = 0; }
     }
     if (rown) {  // q|k|v input gradient + SLN1 backward + the residual-stream gradient
-      VG_TRY(row_bwd(w.dqkv, 3 * E, wp + po_wqkvT, h, hb, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w, P + lo + lay.sln1_b,
-                     P + lo + lay.sln1_s, gmid, gin, (drop && l > 0) ? gm2buf : nullptr, 1, w.part + (size_t)(2 * l + 1) * part_sz, 101 + 2 * (l - 1)));
+      VG_TRY(row_bwd(dqkv_l, 3 * E, wp + po_wqkvT, h, hb, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w, P + lo + lay.sln1_b,
+                     P + lo + lay.sln1_s, gmid, gin, (drop && l > 0) ? gm2_of(l - 1) : nullptr, 1, w.part + (size_t)(2 * l + 1) * part_sz, 101 + 2 * (l - 1)));
     } else {
       VG_TRY(vg_sln_bwd_launch(w.ds, h, hb, w.wmod, w.mean1 + (size_t)l * R, w.rstd1 + (size_t)l * R, P + lo + lay.sln1_w,
                                P + lo + lay.sln1_b, P + lo + lay.sln1_s, P + lo + lay.sln1_s + 1, gmid, gin, w.dw_acc, 1, w.part + (size_t)(2 * l + 1) * part_sz, R, E,
-                               (drop && l > 0) ? gm2buf : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
+                               (drop && l > 0) ? gm2_of(l - 1) : nullptr, dr.thr, site_key(dr, 101 + 2 * (l - 1)), dr.scale, dr.step, st));
     }
     float* bm_prev = (l > 0) ? G + (lo - lay.layer_stride) + lay.bm : nullptr;
     VG_TRY(vg_fold_push(folds, w.part + (size_t)(2 * l + 1) * part_sz, parts, PW, G + lo + lay.sln1_w, E, G + lo + lay.sln1_b, E, bm_prev, E, G + lo + lay.sln1_s, 2));
     bf16* t = g; g = gin; gin = t;
   }
+  if (npend == 1) VG_TRY(gen_wgrad(pend[0], 1));  // the odd block out of this call
   VG_TRY(vg_colsum_f32_multi_launch(folds, st));  // all SLN partial sums queued by this call in one launch
   if (stage_end < d.L + 2) return 0;
   // learned embedding (generator.py:24-26,62) is broadcast over the batch: its gradient is the batch sum
