@@ -947,23 +947,26 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
     d_rows = w.dy2;
   }
   VG_TRY(vg_sin_grad_launch(d_rows, w.zf2, w.dz2, (long long)R * d.CW, d.omega0, st));
-  // bias gradients of the two SIREN layers: partial column sums now, folded with the SLN partials at the end of this call
-  VG_TRY(vg_colsum_bf16_part_launch(w.dz2, d.CW, R, d.CW, w.part_cs2, st));
-  VG_TRY(vg_fold_push(folds, w.part_cs2, vg_colsum_bf16_nparts(R), d.CW, G + lay.s2_b, d.CW, nullptr, 0, nullptr, 0, nullptr, 0));
+  // bias gradients of the two SIREN layers = column sums of the weight gradients' dY operands: they ride along in those GEMMs (ones x dY on the
+  // MFMA pipe, one row per K slice - two 11 us column-sum launches less) and are folded with the SLN partials at the end of this call
   {
-    const int splits = pick_splits(tiles128(d.CW, d.O), R, GEN_SPLIT_CAP);
+    int splits = pick_splits(tiles128(d.CW, d.O), R, GEN_SPLIT_CAP);
+    if (splits > vg_colsum_bf16_nparts(R)) splits = vg_colsum_bf16_nparts(R);  // (part_cs2 holds that many rows)
     VgGemmProb p = wg(w.dz2, d.CW, w.y1, d.O, R, w.slab, (long long)d.CW * d.O, splits);
+    p.colsum = w.part_cs2; p.colsum_split_stride = d.CW;
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.CW * d.O, p.splits, G + lay.s2_w, (long long)d.CW * d.O, 1, st));
+    VG_TRY(vg_fold_push(folds, w.part_cs2, p.splits, d.CW, G + lay.s2_b, d.CW, nullptr, 0, nullptr, 0, nullptr, 0));
   }
   VG_TRY(lin_dgrad(w.dz2, Pb + lay.s2_w, w.dz1, R, d.CW, d.O, VG_ACT_MUL_COS, nullptr, w.zf1, d.omega0, st));
-  VG_TRY(vg_colsum_bf16_part_launch(w.dz1, d.O, R, d.O, w.part_cs, st));
-  VG_TRY(vg_fold_push(folds, w.part_cs, vg_colsum_bf16_nparts(R), d.O, G + lay.s1_b, d.O, nullptr, 0, nullptr, 0, nullptr, 0));
   {
-    const int splits = pick_splits(tiles128(d.O, E), R, GEN_SPLIT_CAP);
+    int splits = pick_splits(tiles128(d.O, E), R, GEN_SPLIT_CAP);
+    if (splits > vg_colsum_bf16_nparts(R)) splits = vg_colsum_bf16_nparts(R);
     VgGemmProb p = wg(w.dz1, d.O, w.sf, E, R, w.slab, (long long)d.O * E, splits);
+    p.colsum = w.part_cs; p.colsum_split_stride = d.O;
     VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)d.O * E, p.splits, G + lay.s1_w, (long long)d.O * E, 1, st));
+    VG_TRY(vg_fold_push(folds, w.part_cs, p.splits, d.O, G + lay.s1_b, d.O, nullptr, 0, nullptr, 0, nullptr, 0));
   }
   const bf16* hL = w.hout + (size_t)(d.L - 1) * RE;
   if (rown) {  // first SIREN layer's input gradient + the final SLN's backward
