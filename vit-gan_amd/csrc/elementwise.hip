@@ -491,6 +491,9 @@ __global__ __launch_bounds__(256) void vg_slab_reduce_kernel(const float* __rest
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   f32x4 a = accumulate ? *(const f32x4*)(dst + i4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the slices are added in slice order (the fold is deterministic), but their loads are independent: eight in flight per thread
+  // (the embedding's 32-slice fold is 18 workgroups - one load at a time it took 11 us)
+#pragma unroll 8
   for (int s = 0; s < nslab; ++s) a += *(const f32x4*)(slab + (size_t)s * stride + i4);
   *(f32x4*)(dst + i4) = a;
 }
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(256) void vg_slab_reduce2_kernel(const float* __res
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   f32x4 a = accumulate ? *(const f32x4*)(dst + i4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
   for (int s = 0; s < nslab; ++s) a += *(const f32x4*)(slab + (size_t)s * stride + i4);
   *(f32x4*)(dst + i4) = a;
 }
