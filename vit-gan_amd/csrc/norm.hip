@@ -297,8 +297,10 @@ __global__ __launch_bounds__(256) void vg_colsum_f32_multi_kernel(VgFoldJobs job
   const int width = J.width, rows = J.rows;
   if (blockIdx.x * 16 >= width) return;
   float a = 0.f;
-  if (c < width)
-    for (int r = rl; r < rows; r += 16) a += J.part[(size_t)r * width + c];
+  if (c < width) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += 16) a += J.part[(size_t)r * width + c];  // (same order of additions; the loads of eight rows in flight)
+  }
   red[rl][cl] = a;
   __syncthreads();
   if (rl != 0 || c >= width) return;
