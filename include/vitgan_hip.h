@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 7
+#define VG_ABI_VERSION 8
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -110,6 +110,19 @@ int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias, const voi
 int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
                            const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
                            float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
+
+/* The MLP half of an encoder block as ONE launch (csrc/chain.hip; E = 384, hidden 768):
+ *   a1 = gelu(xn W1^T + b1);  Y = res + drop(a1 W2^T + b2);  Yn = LayerNorm(Y) * gamma + beta, mean / rstd of Y   (Yn NULL: Y only)
+ * replaces fc1 -> nn.GELU -> fc2 -> dropout -> residual add of src/v2/modules.py:181-182 and the LayerNorm that reads the sum
+ * (the next block's norm1, :168 / :178).  A wave keeps its 16 rows in registers for the whole chain: the hidden a1 [M,768] and
+ * dcode [M,768] (gelu' as byte codes, as vg_linear_gelu_fwd) are written for the backward and never read back.
+ * The weights come as a chain image: img = vg_encoder_mlp_pack(W1 [768,384], W2 [384,768]), vg_encoder_mlp_image_elems() bf16.
+ * M % 16 == 0; other shapes return -3 and the caller uses vg_linear_gelu_fwd + vg_linear_ln_fwd.  drop(.) as in vg_linear_ln_fwd. */
+long long vg_encoder_mlp_image_elems(void); /* host only */
+int vg_encoder_mlp_pack(const void* W1, const void* W2, void* img, void* stream);
+int vg_encoder_mlp_fwd(const void* xn, const void* img, const float* b1, const float* b2, const void* res, void* a1, void* dcode,
+                       void* Y, void* Yn, float* mean, float* rstd, const float* gamma, const float* beta, int M, float eps,
+                       float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
 
 /* The same two kernels with the v1 generator's self-modulated LayerNorm (src/v1/spectral_layer_norm.py:19-20) in the epilogue:
  * vg_linear_sln_fwd:  Y = (res | resf[row % res_period]) + drop(A Wp^T + bias);  Yn = w * (gs * (LN(Y) * lw + lb) + bs)

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VITGAN_HIP_LIB", os.path.join(_HERE, "libvitgan_hip.s
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
-ABI_VERSION = 7  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
+ABI_VERSION = 8  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
 
 
 class VgVitDims(C.Structure):
@@ -80,6 +80,9 @@ _SIGNATURES = {
     "vg_row_parts": (c_int, [c_int]),
     "vg_linear_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_dgrad_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_encoder_mlp_image_elems": (c_ll, []),
+    "vg_encoder_mlp_pack": (c_int, [P, P, P, P]),
+    "vg_encoder_mlp_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_sln_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_dgrad_sln_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),

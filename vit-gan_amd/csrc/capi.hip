@@ -2,6 +2,7 @@
 #include "../../include/vitgan_hip.h"
 #include "vg_kernels.h"
 #include "vg_row.h"
+#include "vg_chain.h"
 
 extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
 
@@ -146,6 +147,24 @@ extern "C" int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias
   ra.Y = (bf16*)Y; ra.Yn = (bf16*)Yn; ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = eps;
   row_drop(ra, drop_p, seed, site, step_dev);
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
+extern "C" long long vg_encoder_mlp_image_elems(void) { return (long long)VG_CH_MLP_STAGES * VG_CH_STAGE / 2; }
+extern "C" int vg_encoder_mlp_pack(const void* W1, const void* W2, void* img, void* stream) {
+  return vg_chain_mlp_pack_launch((const bf16*)W1, (const bf16*)W2, (bf16*)img, VG_CH_KNAT, (hipStream_t)stream);
+}
+extern "C" int vg_encoder_mlp_fwd(const void* xn, const void* img, const float* b1, const float* b2, const void* res, void* a1,
+                                  void* dcode, void* Y, void* Yn, float* mean, float* rstd, const float* gamma, const float* beta,
+                                  int M, float eps, float drop_p, unsigned long long seed, int site, const unsigned* step_dev,
+                                  void* stream) {
+  if (!xn || !img || !b1 || !b2 || !a1 || !dcode || !Y || (Yn && (!mean || !rstd || !gamma || !beta)) || drop_p < 0.f || drop_p >= 1.f) return -1;
+  VgChainMlpArgs ca = {};
+  ca.xn = (const bf16*)xn; ca.ldx = VG_CH_E; ca.img = (const bf16*)img; ca.b1 = b1; ca.b2 = b2; ca.res = (const bf16*)res;
+  ca.a1 = (bf16*)a1; ca.z8 = (unsigned char*)dcode; ca.Y = (bf16*)Y; ca.Yn = (bf16*)Yn; ca.mean_out = mean; ca.rstd_out = rstd;
+  ca.gamma = gamma; ca.beta = beta; ca.eps = eps; ca.M = M;
+  int t = (int)lrintf(drop_p * 256.f); if (t < 0) t = 0; if (t > 255) t = 255;
+  if (t) { ca.drop_thresh = (unsigned)t; ca.drop_key = vg_site_key(seed, site); ca.drop_scale = 256.f / (256.f - t); ca.drop_step = step_dev; }
+  const int r = vg_chain_mlp_fwd_launch(ca, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
 extern "C" int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
