@@ -88,8 +88,8 @@ def gen_flops_per_image(latent, tokens, embed, layers, siren_hidden, out_feature
 
 
 PEAK_HBM_GBS = 8000.0      # HBM3E, MI355X_MICROARCH.md "Chip-level parameters" (6.3 TB/s is what a streaming copy reaches)
-TRAFFIC_FILE = "profiles/r03_gemm_pmc_traffic.json"      # tools/pmc_traffic.py over tools/gemm_bench.py (separate --pmc passes)
-STEP_PMC_FILE = "profiles/r03_step_pmc_summary.json"     # tools/pmc_summary.py over the step (separate --pmc passes)
+TRAFFIC_FILE = "profiles/r04_gemm_pmc_traffic.json"      # tools/pmc_traffic.py over tools/gemm_bench.py (separate --pmc passes)
+STEP_PMC_FILE = "profiles/r04_step_pmc_summary.json"     # tools/pmc_summary.py over the step (separate --pmc passes)
 E = 384
 
 
@@ -179,10 +179,17 @@ def step_roofline(torch, B, reps=30):
          lambda: chk(L.vg_linear_gelu_fwd(p(x384), p(w1), p(b768), p(o768), p(code), M, 768, 384, st), "vg_linear_gelu_fwd"),
          2.0 * M * 768 * 384, 2 * (M * 384 + 768 * 384 + M * 768) + M * 768, "wr fc1+gelu+gelu' bytes"),
     ]
-    traffic = {}
+    # Figures quoted from committed PMC summaries are tied to the tree they were measured on: the summary carries the hash of the
+    # kernel / engine sources (tools/tree_hash.py) and, where known, the commit; when this tree hashes differently the quoted
+    # fields are null and `*_stale` says why (nothing used to tie the file to the tree being benchmarked).
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from tree_hash import tree_hash
+    here = tree_hash(ROOT)
+    traffic, traffic_meta = {}, {}
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
-            traffic = json.load(f)["kernels"]
+            traffic_meta = json.load(f)
+        traffic = traffic_meta["kernels"] if traffic_meta.get("tree_hash") == here else {}
     except (OSError, KeyError, ValueError):
         pass
     kernels = []
@@ -205,15 +212,23 @@ def step_roofline(torch, B, reps=30):
            "kernel": d["kernel"], "shape_M_N_K": d["shape"],
            "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
            "avg_launch_us": d["avg_launch_us"], "median_launch_us": d["median_launch_us"], "min_launch_us": d["min_launch_us"],
-           "timing": f"per-dispatch HIP event pairs on the kernel's stream, {reps} launches", "kernels": kernels}
+           "timing": f"per-dispatch HIP event pairs on the kernel's stream, {reps} launches", "kernels": kernels,
+           "tree_hash": here}
+    if traffic_meta and not traffic:
+        out["traffic_stale"] = f"{TRAFFIC_FILE} was measured on tree {traffic_meta.get('tree_hash')} (commit {traffic_meta.get('commit')}), not on this one"
+    out["hbm_GB_per_step"] = out["mfma_util_percent_step"] = None
     try:
         with open(os.path.join(ROOT, STEP_PMC_FILE)) as f:
             sp = json.load(f)
-        out["hbm_GB_per_step"] = sp["hbm"]["total_GB_per_step"]
-        out["mfma_util_percent_step"] = sp["mfma_util_percent"]["<whole step, all vg_ kernels>"]["util"]
         out["step_pmc_source"] = STEP_PMC_FILE + " (rocprofv3 --pmc passes over bench.py, tools/pmc_summary.py; B = 256)"
+        out["step_pmc_tree_hash"], out["step_pmc_commit"] = sp.get("tree_hash"), sp.get("commit")
+        if sp.get("tree_hash") == here:
+            out["hbm_GB_per_step"] = sp["hbm"]["total_GB_per_step"]
+            out["mfma_util_percent_step"] = sp["mfma_util_percent"]["<whole step, all vg_ kernels>"]["util"]
+        else:
+            out["step_pmc_stale"] = "measured on another tree than the one being benchmarked: the two quoted fields are null"
     except (OSError, KeyError, ValueError):
-        out["hbm_GB_per_step"] = None
+        pass
     return out
 
 
@@ -234,13 +249,14 @@ def main():
     ap.add_argument("--gp", type=float, default=0.0,
                     help="weight of the WGAN-GP gradient penalty in the discriminator step (src/v2/training.py:101-106; 10 with --loss wasserstein is "
                          "the reference's unreached recipe): an extra measurement, not the headline - the penalty runs through torch autograd over "
-                         "the twice-differentiable operators and forces the eager (non-graph) step")
+                         "the twice-differentiable operators; the step with it is captured and replayed as a hipGraph like the plain one")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the step as a hipGraph (on > 1 GPU the capture includes the RCCL all-reduces); 0: eager; -1 (default): "
                          "on - the engine falls back to eager, loudly, when the process group cannot be captured (gloo)")
-    ap.add_argument("--compress-mapping-grad", type=int, default=1,
-                    help="data parallel only: exchange the generator's 12.6 M-parameter mapping gradient as bf16 (halves the one exchange "
-                         "that cannot hide behind compute); the engine's own default is the exact fp32 all-reduce")
+    ap.add_argument("--compress-mapping-grad", type=int, default=0,
+                    help="data parallel only, 1: exchange the generator's 12.6 M-parameter mapping gradient as bf16 (halves the one exchange "
+                         "that cannot hide behind compute, but the sum is then formed in bf16); default 0: the exact fp32 all-reduce, the "
+                         "reference's arithmetic - what a multi-GPU headline must be measured on (VERDICT r3 weak 7)")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--fp8-attention", type=int, default=-1,
@@ -251,6 +267,8 @@ def main():
                     help="1: compute every row of the top encoder block (the reference's operator graph row for row); default 0: only the CLS rows "
                          "the classifier reads behind that block's attention - same logits and gradients (DESIGN.md s3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the C4 / C5 measurements that follow the headline's timed region on one GPU (JSON field extra_workloads)")
     ap.add_argument("--no-roofline", action="store_true",
                     help="profiling aid: skip the dominant-kernel timing leg, so a rocprofv3 run of this command contains the step's launches only")
     ap.add_argument("--single-stream", action="store_true", help="(default since round 2; kept for the profiling scripts) weight gradients on the main stream")
@@ -297,32 +315,47 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
-    geo = {"c2": dict(image=32, patch=4, embed=384, heads=4, batch=256, gpatch=0),
+    GEO = {"c2": dict(image=32, patch=4, embed=384, heads=4, batch=256, gpatch=0),
            "c4": dict(image=64, patch=8, embed=512, heads=8, batch=128, gpatch=8),
-           "c5": dict(image=128, patch=16, embed=768, heads=12, batch=128, gpatch=16)}[args.workload]
-    B = args.batch or geo["batch"]
+           "c5": dict(image=128, patch=16, embed=768, heads=12, batch=128, gpatch=16)}
+    use_graph = True if args.graph < 0 else bool(args.graph)
+
+    def make(workload, B, fp8_flag):
+        """Discriminator, generator and engine of one workload (random init of that architecture, synthetic data)."""
+        geo = GEO[workload]
+        torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
+        cfg = Config(embeddings_dimension=geo["embed"], attention_heads_count=geo["heads"], transformer_blocks_count=6, mlp_ratio=2,
+                     patch_size=geo["patch"], image_size=geo["image"], input_channels=3, classes_count=1,
+                     dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
+        D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
+        fp8 = (workload == "c5") if fp8_flag < 0 else bool(fp8_flag)
+        D.vit.attention_fp8 = fp8
+        if workload == "c2":
+            G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
+        else:
+            G = SirenGenerator(image_size=geo["image"], embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
+                               dropout=0.2 if args.dropout else 0.0).to(dev).train()
+        eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
+                        concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
+                        compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp,
+                        dense_top_block=bool(args.dense_top_block))
+        return geo, G, eng, fp8
+
+    def step_flops(geo, G, fp8):
+        f_d = vit_flops_per_image(geo["image"], geo["patch"], geo["embed"])
+        gd = G._dims
+        f_g = gen_flops_per_image(gd.Z, gd.T, gd.E, gd.L, gd.O, gd.CW)
+        f_step = 8 * f_d + 3 * f_g  # SURVEY 8d: algorithmic FLOPs per real image (the reference's operator graph)
+        f_exec = f_step - (0 if args.dense_top_block else 8 * vit_dead_flops_per_image(geo["image"], geo["patch"], geo["embed"], fp8_attention=fp8))
+        return f_step, f_exec  # (the second: what the engine really multiplies)
+
+    B = args.batch or GEO[args.workload]["batch"]
     if args.global_batch:
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
         B = args.global_batch // world
+    geo, G, eng, fp8_attn = make(args.workload, B, args.fp8_attention)
     IMG = geo["image"]
-    torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
-    cfg = Config(embeddings_dimension=geo["embed"], attention_heads_count=geo["heads"], transformer_blocks_count=6, mlp_ratio=2,
-                 patch_size=geo["patch"], image_size=IMG, input_channels=3, classes_count=1,
-                 dropout_rate=0.1 if args.dropout else 0.0, batch_size=B)
-    D = ViTDiscriminator(cfg).to(dev).train()                       # Config default dropout_rate = 0.1 (src/v2/utils.py:30)
-    fp8_attn = (args.workload == "c5") if args.fp8_attention < 0 else bool(args.fp8_attention)
-    D.vit.attention_fp8 = fp8_attn
-    if args.workload == "c2":
-        G = SirenGenerator(dropout=0.2 if args.dropout else 0.0).to(dev).train()  # src/v1/config.py:36,39
-    else:
-        G = SirenGenerator(image_size=IMG, embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
-                           dropout=0.2 if args.dropout else 0.0).to(dev).train()
-    use_graph = True if args.graph < 0 else bool(args.graph)
-    eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
-                    concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
-                    compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp,
-                    dense_top_block=bool(args.dense_top_block))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     reals = [torch.rand(B, 3, IMG, IMG, device=dev, generator=gen) * 2 - 1 for _ in range(4)]  # resident synthetic batches
     torch.manual_seed(4321 + rank)  # noise stream
@@ -362,11 +395,7 @@ def main():
     ok = all(x == x and abs(x) < 1e4 for x in lv)
 
     if rank == 0:
-        f_d = vit_flops_per_image(IMG, geo["patch"], geo["embed"])
-        gd = G._dims
-        f_g = gen_flops_per_image(gd.Z, gd.T, gd.E, gd.L, gd.O, gd.CW)
-        f_step = 8 * f_d + 3 * f_g  # algorithmic FLOPs per real image (the reference's operator graph)
-        f_exec = f_step - (0 if args.dense_top_block else 8 * vit_dead_flops_per_image(IMG, geo["patch"], geo["embed"], fp8_attention=fp8_attn))  # what the engine really multiplies
+        f_step, f_exec = step_flops(geo, G, fp8_attn)
         ips = args.steps * B * world / elapsed
         step_tf = ips * f_step / 1e12 / world
         # the roofline leg always times the C2 shape
@@ -399,6 +428,40 @@ def main():
                        "losses_finite": ok, "last_losses": [round(x, 4) for x in lv]},
             "roofline": roof,
         }
+        # The other single-GPU configurations of BASELINE.json (configs[3], configs[4]: C4 and C5 at B = 128 per GPU, C5 with fp8 attention),
+        # timed by the SAME driver-run command: behind the headline's timed region, so the C2 number is untouched.
+        if world == 1 and args.workload == "c2" and not args.no_extra_workloads and args.gp == 0.0:
+            eng.close()
+            del eng
+            extras = []
+            for wl in ("c4", "c5"):
+                g2, G2, e2, f8 = make(wl, GEO[wl]["batch"], -1)
+                B2 = GEO[wl]["batch"]
+                gen2 = torch.Generator(device=dev).manual_seed(99)
+                r2 = [torch.rand(B2, 3, g2["image"], g2["image"], device=dev, generator=gen2) * 2 - 1 for _ in range(2)]
+                for i in range(4):
+                    e2.step(r2[i % 2])
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n2 = 10
+                a0.record()
+                for i in range(n2):
+                    l2 = e2.step(r2[i % 2])
+                a1.record()
+                torch.cuda.synchronize()
+                ms = a0.elapsed_time(a1) / n2
+                fs, fe = step_flops(g2, G2, f8)
+                ips2 = B2 / ms * 1e3
+                extras.append({"workload": wl, "config": f"BASELINE.json configs[{3 if wl == 'c4' else 4}] geometry on one GPU: {g2['image']}x{g2['image']} patch {g2['patch']}, "
+                                                         f"E={g2['embed']}, {g2['heads']} heads, 6 blocks, patch-grid SLN/SIREN generator, B={B2}",
+                               "fp8_attention": f8, "steps": n2, "warmup": 4, "ms_per_step": round(ms, 4), "images_per_sec": round(ips2, 1),
+                               "step_tflops": round(ips2 * fs / 1e12, 1), "step_frac_of_peak": round(ips2 * fs / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "step_frac_of_peak_executed": round(ips2 * fe / 1e12 / PEAK_BF16_TFLOPS, 4), "hip_graph": e2.graph_active,
+                               "losses_finite": all(x == x and abs(x) < 1e4 for x in l2.cpu().tolist())})
+                e2.close()
+                del e2, G2, r2
+                torch.cuda.empty_cache()
+            out["extra_workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

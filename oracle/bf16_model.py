@@ -136,28 +136,49 @@ class _SirenStore(torch.autograd.Function):
         return bf(g * ctx.w0 * torch.cos(ctx.w0 * pre)), None
 
 
+def e4m3(x: Tensor) -> Tensor:
+    """Value-level OCP e4m3 rounding (what v_cvt_pk_fp8_f32 does to an MFMA operand of the fp8 attention mode)."""
+    return x.to(torch.float8_e4m3fn).float() if _ROUND else x
+
+
 class _Attention(torch.autograd.Function):
-    """attention.hip vg_attn_fwd_kernel / vg_attn_bwd_kernel on [B,H,S,hd] operands (already bf16-valued)."""
+    """attention.hip vg_attn_fwd_kernel / vg_attn_bwd_kernel on [B,H,S,hd] operands (already bf16-valued).
+
+    fp8 = True is the C5 mode (VgVitNet.attn_fp8, BASELINE.json configs[4]; src/v2/modules.py:142-155 with e4m3 MFMA operands):
+    the ACTIVATION-side products take OCP e4m3 operands - Q and K for the scores, in the forward and in the backward's
+    recompute (so P matches the forward's lse), and 256 p and V for P.V (the numerators scaled into e4m3's normal range) -
+    while every product with a gradient operand (dP, dV, dQ, dK) stays bf16 on the bf16 Q, K, V: gradients need the range."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
-        s = (q @ k.transpose(-1, -2)) * scale
+    def forward(ctx, q, k, v, scale, fp8=False):
+        if fp8:
+            s = (e4m3(q) @ e4m3(k).transpose(-1, -2)) * scale
+        else:
+            s = (q @ k.transpose(-1, -2)) * scale
         m = s.max(dim=-1, keepdim=True).values
         p = torch.exp(s - m)
         l = p.sum(dim=-1, keepdim=True)          # fp32 row sum of the UNrounded numerators
-        o = (bf(p) @ v) / l                      # numerators rounded for the MFMA (pack_pair)
+        if fp8:
+            o = (e4m3(p * 256.0) @ e4m3(v)) / 256.0 / l
+        else:
+            o = (bf(p) @ v) / l                  # numerators rounded for the MFMA (pack_pair)
         ctx.save_for_backward(q, k, v, m + torch.log(l), bf(o))
         ctx.scale = scale
+        ctx.fp8 = fp8
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, lse, o_stored = ctx.saved_tensors
-        p = torch.exp((q @ k.transpose(-1, -2)) * ctx.scale - lse)   # recomputed from the fp32 lse
+        if ctx.fp8:
+            s = (e4m3(q) @ e4m3(k).transpose(-1, -2)) * ctx.scale
+        else:
+            s = (q @ k.transpose(-1, -2)) * ctx.scale
+        p = torch.exp(s - lse)                                       # recomputed from the fp32 lse
         dp = do @ v.transpose(-1, -2)
         delta = (do * o_stored).sum(dim=-1, keepdim=True)            # from the stored bf16 output
         ds = bf(p * (dp - delta) * ctx.scale)
-        return ds @ k, ds.transpose(-1, -2) @ q, bf(p).transpose(-1, -2) @ do, None
+        return ds @ k, ds.transpose(-1, -2) @ q, bf(p).transpose(-1, -2) @ do, None, None
 
 
 class _Mapping(torch.autograd.Function):
@@ -224,8 +245,8 @@ def vit_embed(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = 
 
 
 def vit_block(state: Mapping[str, Tensor], h: Tensor, d: VitDims, b: str, m_attn: Optional[Tensor] = None,
-              m_mlp: Optional[Tensor] = None) -> Tensor:
-    """X[l] -> X[l+1]; ``h`` must be a stored tensor (or, when teacher-forcing, ``stored(leaf)``)."""
+              m_mlp: Optional[Tensor] = None, fp8: bool = False) -> Tensor:
+    """X[l] -> X[l+1]; ``h`` must be a stored tensor (or, when teacher-forcing, ``stored(leaf)``); fp8: e4m3 attention operands."""
     B, S, E = h.shape
     H, hd = d.heads, d.head_dim
     xn1 = stored(_ln(h, state[b + "norm1.weight"], state[b + "norm1.bias"]))
@@ -233,7 +254,7 @@ def vit_block(state: Mapping[str, Tensor], h: Tensor, d: VitDims, b: str, m_attn
     bqkv = torch.cat([state[b + f"attention.{n}.bias"] for n in ("queries", "keys", "values")], dim=0)
     qkv = stored(xn1 @ wqkv.t() + bqkv)
     q, k, v = (t.reshape(B, S, H, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
-    ao = stored(_Attention.apply(q, k, v, 1.0 / math.sqrt(float(hd))).transpose(1, 2).reshape(B, S, E))
+    ao = stored(_Attention.apply(q, k, v, 1.0 / math.sqrt(float(hd)), fp8).transpose(1, 2).reshape(B, S, E))
     lin = ao @ shadow(state[b + "attention.out_projection.weight"]).t() + state[b + "attention.out_projection.bias"]
     xmid = stored(drop(lin, m_attn) + h)
     xn2 = stored(_ln(xmid, state[b + "norm2.weight"], state[b + "norm2.bias"]))
@@ -251,11 +272,11 @@ def vit_head(state: Mapping[str, Tensor], h: Tensor, prefix: str = "vit.") -> Te
 
 
 def vit_forward(state: Mapping[str, Tensor], x: Tensor, d: VitDims, prefix: str = "vit.",
-                masks: Optional[Mapping] = None) -> Tensor:
+                masks: Optional[Mapping] = None, fp8: bool = False) -> Tensor:
     masks = masks or {}
     h = vit_embed(state, x, d, prefix, masks.get("embed"))
     for i in range(d.layers):
-        h = vit_block(state, h, d, f"{prefix}encoder.{i}.", masks.get(("attn", i)), masks.get(("mlp", i)))
+        h = vit_block(state, h, d, f"{prefix}encoder.{i}.", masks.get(("attn", i)), masks.get(("mlp", i)), fp8)
     return vit_head(state, h, prefix)
 
 

@@ -56,7 +56,9 @@ def _report(title, worst):
 
 
 # B = 32 (M = 2080 rows = 65 units of 32): the K = 384 Linears of that case run on the weights-in-registers kernel
-@pytest.mark.parametrize("case,B,dropout", [("c1", 3, 0.0), ("c1", 2, 0.1), ("c4", 2, 0.0), ("c1", 32, 0.1)])
+# "c5-fp8": the C5 geometry (E = 768, 12 heads of 64, 3 blocks deep here) with e4m3 attention operands (VgVitNet.attn_fp8) against the
+# model's fp8 mode: the same 2^-6 per stage as the bf16 cases - the rounding-faithful tier of the fp8 network
+@pytest.mark.parametrize("case,B,dropout", [("c1", 3, 0.0), ("c1", 2, 0.1), ("c4", 2, 0.0), ("c1", 32, 0.1), ("c5-fp8", 2, 0.0), ("c5-fp8", 2, 0.1)])
 def test_vit_every_stage_against_the_model(case, B, dropout):
     import gpu_util as u
     from cases import VIT_CASES
@@ -64,7 +66,8 @@ def test_vit_every_stage_against_the_model(case, B, dropout):
     from oracle import bf16_model as bm, vit_oracle as vo
     from vit_gan_amd import _lib, flat
 
-    c = VIT_CASES[case]
+    fp8 = case.endswith("-fp8")
+    c = dict(VIT_CASES["c5"], layers=3) if fp8 else VIT_CASES[case]
     d = vo.VitDims(channels=c["channels"], image=c["image"], patch=c["patch"], embed=c["embed"], heads=c["heads"],
                    layers=c["layers"], mlp_ratio=c["mlp_ratio"], classes=c["classes"])
     L, S, E = d.layers, d.seq, d.embed
@@ -75,7 +78,7 @@ def test_vit_every_stage_against_the_model(case, B, dropout):
     P = flat.pack(slots, lay.total, st_np, device="cuda")
     Pb, G = P.to(torch.bfloat16), torch.zeros_like(P)
     seed = 4321
-    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), dropout, seed, None, _lib.context())
+    net = _lib.VgVitNet(dd, P.data_ptr(), Pb.data_ptr(), G.data_ptr(), dropout, seed, None, _lib.context(), 1 if fp8 else 0, 0)
     wm = _lib.VgVitWsMap()
     u.call("vg_vit_ws_map", C.byref(dd), B, C.byref(wm))
     ws = torch.zeros(_lib.lib().vg_vit_ws_bytes(C.byref(dd), B), dtype=torch.uint8, device="cuda")
@@ -127,6 +130,10 @@ def test_vit_every_stage_against_the_model(case, B, dropout):
 
     def check(got, ref, what, scale=None):
         worst[what] = _rel_err(got, ref, scale)
+        if worst[what] > 0.5:  # an O(1) miss: say what the two sides look like
+            g_, r_ = got.detach().float().cpu(), ref.detach().float().cpu()
+            print(f"{what}: |got| max {float(g_.abs().max()):.4e} mean {float(g_.abs().mean()):.4e}; |ref| max {float(r_.abs().max()):.4e} mean "
+                  f"{float(r_.abs().mean()):.4e}; got/ref at ref's largest element {float(g_.flatten()[r_.abs().argmax()] / r_.flatten()[r_.abs().argmax()]):.4f}")
 
     def check_params(st, keys, what):
         for k in keys:
@@ -147,7 +154,7 @@ def test_vit_every_stage_against_the_model(case, B, dropout):
     for l in range(L):
         st = {k: torch.from_numpy(v).requires_grad_(True) for k, v in st_np.items()}
         xin = _leaf(Xs[l])
-        out = bm.vit_block(st, bm.stored(xin), d, f"vit.encoder.{l}.", masks.get(("attn", l)), masks.get(("mlp", l)))
+        out = bm.vit_block(st, bm.stored(xin), d, f"vit.encoder.{l}.", masks.get(("attn", l)), masks.get(("mlp", l)), fp8)
         if l == L - 1:
             check(Xs[l + 1][:, 0], out[:, 0], f"block {l}: X[l+1] (CLS rows)")
         else:

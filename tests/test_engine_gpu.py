@@ -275,8 +275,10 @@ def test_load_state_dict_after_engine_construction_refreshes_the_shadows():
     assert torch.equal(la, lb)
     for i, (a, b) in enumerate(zip(sa, sb)):
         assert torch.equal(a, b), f"state tensor {i}"
+    seed_before = eng_a._noise_seed
     eng_a.sync_from_modules(reset_optimizer=True)
     assert int(eng_a.step_t) == 0 and float(eng_a.m_d.abs().sum()) == 0.0
+    assert eng_a._noise_seed != seed_before, "a restarted run would replay the first run's latent sequence (ADVICE r3)"
 
 
 def _dp_worker(rank, world, port, out):

@@ -132,9 +132,9 @@ def test_full_size_c4_c5_properties(name, dims, fp8):
     E = 768 select other kernels than C2 (the 128x512 / 128x384-tile weight gradients at M = 8 320, the tiled GEMMs with
     contraction 512 / 768 / 2048 / 3072, HE = 64 x 8 / 12 heads, fp8 attention operands), none of which the small fixtures
     reach at full M.  Per-sample bit-independence, determinism, gradient additivity (1e-4), linearity, and 8 images of the
-    batch against the fp32 oracle (bf16 attention: the loose tier of test_net_gpu.py; fp8 operands: logits 2^-3, gradients
-    2^-2 - six e4m3-operand attentions deep, each 7-9.5 % of max from fp32 attention by itself: measured 15 % on
-    block 0's query weights; the fp8 kernel's own reference is the e4m3-operand model of tests/test_ops_gpu.py)."""
+    batch against a CPU reference at the loose tier of test_net_gpu.py (logits 2^-5, gradients 2^-4): the fp32 oracle for the
+    bf16 networks, the rounding-faithful model in its e4m3 mode for C5-fp8 (six e4m3-operand attentions deep the network is
+    7-15 % of max away from fp32 arithmetic - that figure is printed, the fp8 network's bound is the same as the bf16 ones')."""
     B = 128
     _lib, flat, vo, d, st, gd, slots, P, Pb, x = _setup(B, **dims)
     dl = torch.randn(B, 1, generator=torch.Generator().manual_seed(4)) / B
@@ -156,19 +156,38 @@ def test_full_size_c4_c5_properties(name, dims, fp8):
     _, G2x, dimg2x = _run(_lib, gd, P, Pb, x, 2 * dl, fp8=fp8)
     assert torch.equal(G2x, 2 * G) and torch.equal(dimg2x, 2 * dimg)
     import gpu_util as u
+    from oracle import bf16_model as bm
     sl = slice(0, 8)
-    so = {k: v.clone().requires_grad_(True) for k, v in st.items()}
-    xo = x[sl].float().requires_grad_(True)
-    out = vo.vit_forward(so, xo, d)
-    (out * dl[sl]).sum().backward()
     l8, G8, d8 = _run(_lib, gd, P, Pb, x[sl], dl[sl], fp8=fp8)
     assert torch.equal(l8, logits[sl])
-    tl, tg = (2.0 ** -3, 2.0 ** -2) if fp8 else (2.0 ** -5, 2.0 ** -4)
-    u.assert_close(l8, out, tl, f"{name} logits vs oracle")
     g8 = flat.unpack(slots, G8)
-    for k in ("vit.encoder.5.fc2.weight", "vit.encoder.0.attention.queries.weight", "vit.embedding.conv1.weight", "vit.norm.weight"):
-        u.assert_close(g8[k], so[k].grad, tg, f"{name} grad {k}", floor=1e-6)
-    u.assert_close(d8, xo.grad, tg, f"{name} d images", floor=1e-6)
+    keys = ("vit.encoder.5.fc2.weight", "vit.encoder.0.attention.queries.weight", "vit.embedding.conv1.weight", "vit.norm.weight")
+
+    def reference(fn):
+        so = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+        xo = x[sl].float().requires_grad_(True)
+        out = fn(so, xo)
+        (out * dl[sl]).sum().backward()
+        return out.detach(), {k: so[k].grad for k in keys}, xo.grad
+    out, gr, dx = reference(lambda so, xo: vo.vit_forward(so, xo, d))
+    if not fp8:
+        u.assert_close(l8, out, 2.0 ** -5, f"{name} logits vs oracle")
+        for k in keys:
+            u.assert_close(g8[k], gr[k], 2.0 ** -4, f"{name} grad {k}", floor=1e-6)
+        u.assert_close(d8, dx, 2.0 ** -4, f"{name} d images", floor=1e-6)
+        return
+    # fp8 operands: the network's reference is the rounding-faithful model in its e4m3 mode (oracle/bf16_model.py, pinned stage by
+    # stage at 2^-6 in tests/test_blocks_gpu.py), held at the SAME whole-network tier as the bf16 networks: logits 2^-5, gradients
+    # 2^-4.  The distance to fp32 arithmetic is what e4m3's 3 mantissa bits cost six attentions deep: printed, not asserted.
+    def rel(a, b):
+        return float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    print(f"{name}: distance to the fp32 oracle (not a bound): logits {rel(l8, out):.3f}, "
+          + ", ".join(f"{k.split('vit.')[1]} {rel(g8[k], gr[k]):.3f}" for k in keys) + f", d images {rel(d8, dx):.3f}")
+    out, gr, dx = reference(lambda so, xo: bm.vit_forward(so, xo, d, fp8=True))
+    u.assert_close(l8, out, 2.0 ** -5, f"{name} logits vs the e4m3-operand model")
+    for k in keys:
+        u.assert_close(g8[k], gr[k], 2.0 ** -4, f"{name} grad {k} vs the e4m3-operand model", floor=1e-6)
+    u.assert_close(d8, dx, 2.0 ** -4, f"{name} d images vs the e4m3-operand model", floor=1e-6)
 
 
 @pytest.mark.parametrize("name,dims,fp8", [("c4", C4, False), ("c5", C5, True)])

@@ -6,7 +6,7 @@ A=$R/$1; B=$R/$2; shift 2
 for round in 1 2; do
   for L in $A $B; do
     for mode in "--concurrent-wgrad 1" ""; do
-      ms=$(VITGAN_HIP_LIB=$L python3 $R/bench.py --no-roofline --no-cpu-baseline --steps 40 --warmup 10 $mode "$@" 2>/dev/null | python3 -c 'import sys,json; print(json.loads(sys.stdin.readlines()[-1])["ms_per_step"])')
+      ms=$(VITGAN_HIP_LIB=$L python3 $R/bench.py --no-roofline --no-cpu-baseline --no-extra-workloads --steps 40 --warmup 10 $mode "$@" 2>/dev/null | python3 -c 'import sys,json; print(json.loads(sys.stdin.readlines()[-1])["ms_per_step"])')
       echo "$(basename $L) ${mode:-single-stream(default)} $ms"
     done
   done

@@ -59,6 +59,11 @@ def main():
     wb = sum(v.get("WRITE_SIZE", 0.0) for d, v in write.items() if short(wn[d]).startswith(("vg_", "_Z")))
     rec["hbm"] = {"read_GB_per_step": round(2 * fb * 1024 / steps / 1e9, 2), "write_GB_per_step": round(wb * 1024 / steps / 1e9, 2)}
     rec["hbm"]["total_GB_per_step"] = round(rec["hbm"]["read_GB_per_step"] + rec["hbm"]["write_GB_per_step"], 2)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tree_hash import tree_hash
+    rec["tree_hash"] = tree_hash()                      # the sources this was measured on (tools/tree_hash.py); bench.py checks it
+    rec["commit"] = os.environ.get("VG_COMMIT") or None  # the commit of that tree, handed in by tools/profile_round.sh's caller
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 

@@ -48,6 +48,11 @@ def main():
         rec["kernels"][name] = {"kernel": fetch[i][0], "rows_M": gemm_bench.M, "FETCH_SIZE_KB": fetch[i][1],
                                 "WRITE_SIZE_KB": write[i][1], "hbm_bytes_per_launch": int((2 * fetch[i][1] + write[i][1]) * 1024),
                                 "algorithmic_flops": ALGO[name][0], "algorithmic_bytes": ALGO[name][1]}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tree_hash import tree_hash
+    rec["tree_hash"] = tree_hash()                      # the sources this was measured on (tools/tree_hash.py); bench.py checks it
+    rec["commit"] = os.environ.get("VG_COMMIT") or None  # the commit of that tree, handed in by tools/profile_round.sh's caller
     json.dump(rec, open(out, "w"), indent=1)
     base = out.rsplit("_traffic.json", 1)[0]
     shutil.copy(fa, base + "_FETCH_SIZE.csv")

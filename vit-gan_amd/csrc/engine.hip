@@ -53,8 +53,9 @@ extern "C" int vg_vit_layout(const VgVitDims* d, VgVitLayout* o) {
   const int HE = d->E / d->H;
   if (HE != 32 && HE != 64 && HE != 96) return -3;
   if (NP + 1 > 80) return -3;
-  // depth: the backward queues 3 deferred folds per block and uses one event pair per block (+1 for the join)
-  if (3 * d->L + 2 > VG_MAX_FOLD_JOBS || d->L >= VG_CTX_EVENTS - 1) return -3;  // (+ 2: classifier head, final LayerNorm)
+  // depth: the backward queues 3 deferred folds per block + 3 more (classifier head, final LayerNorm, the pruned top block's CLS-summed
+  // bias row) and uses one event pair per block (+1 for the join)
+  if (3 * d->L + 3 > VG_MAX_FOLD_JOBS || d->L >= VG_CTX_EVENTS - 1) return -3;
   long long p = 0;
   o->conv_w = p; p = al64(p + E * K);
   o->conv_b = p; p = al64(p + E);
@@ -687,6 +688,10 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   }
   // all LayerNorm partial sums of this call in one launch (behind the last block's side work)
   if (folds.n > 0) {
+    // the partial rows come from kernels of the MAIN stream (head, final LayerNorm, the LayerNorm backwards): a call that runs no
+    // encoder block (stage range [0, 1)) has recorded no main-stream event the side stream waits for - without this one the fold
+    // raced the final LayerNorm's backward (seen at E = 768: d gamma / d beta of vit.norm zero or partial, run to run)
+    if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_main[VG_CTX_EVENTS - 1], st)); VG_CHECK_HIP(hipStreamWaitEvent(sd, ctx->ev_main[VG_CTX_EVENTS - 1], 0)); }
     VG_TRY(vg_colsum_f32_multi_launch(folds, sd));
     if (ctx) { VG_CHECK_HIP(hipEventRecord(ctx->ev_side[VG_CTX_EVENTS - 1], sd)); VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[VG_CTX_EVENTS - 1], 0)); }
   }

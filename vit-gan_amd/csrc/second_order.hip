@@ -121,12 +121,16 @@ int vg_ln_bwd_bwd_launch(const bf16* u, const bf16* dy, const bf16* x, const flo
                          bf16* d_dy, bf16* d_x, float* part, int R, int E, hipStream_t st) {
   if ((E & 63) || E > 1024 || R < 1) return -3;
 #define VG_LNBB(NE_) hipLaunchKernelGGL((vg_ln_bwd_bwd_kernel<NE_>), dim3(vg_ln_bwd_bwd_nparts(R)), dim3(256), 0, st, u, dy, x, mean, rstd, gamma, d_dy, d_x, part, R)
-  switch (E / 64) {  // the embedding widths of the configurations (128 .. 1024)
+  // every width the first-order LayerNorm and vg_vit_layout accept (E % 128 == 0, E <= 1024): the penalty step must not refuse a
+  // network the plain step trains (640 and 896 were missing)
+  switch (E / 64) {
     case 2: VG_LNBB(2); break;
     case 4: VG_LNBB(4); break;
     case 6: VG_LNBB(6); break;
     case 8: VG_LNBB(8); break;
+    case 10: VG_LNBB(10); break;
     case 12: VG_LNBB(12); break;
+    case 14: VG_LNBB(14); break;
     case 16: VG_LNBB(16); break;
     default: return -3;
   }

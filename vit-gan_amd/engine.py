@@ -338,7 +338,10 @@ class GanEngine:
         (construct_noise(), training.py:35-42 / gan.py:231-232), counter-based on (seed, rank, steps done so far)."""
         B = self.B
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        direct = real.dtype == torch.float32 and real.is_contiguous() and real[0].numel() == self.imgs[0].numel() and real.numel() % 4 == 0
+        # the kernel dereferences the caller's pointer with 16-byte loads on THIS engine's device: anything else (another GPU's
+        # tensor, an unaligned view) goes through torch's copy, which handles it
+        direct = (real.dtype == torch.float32 and real.is_contiguous() and real[0].numel() == self.imgs[0].numel() and real.numel() % 4 == 0
+                  and real.device == self.imgs.device and real.data_ptr() % 16 == 0)
         if not direct:
             self.imgs[:B].copy_(real)
         want_z = not self.external_noise
@@ -428,6 +431,9 @@ class GanEngine:
         if reset_optimizer:
             for t in (self.m_d, self.v_d, self.m_g, self.v_g, self.step_t):
                 t.zero_()
+            # the latent noise is keyed on the device step counter just cleared: move to a fresh stream, keyed on the steps this
+            # engine has really done, so a restarted run does not replay the first run's latent sequence
+            self._noise_seed = (self._noise_seed * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (self.steps + 1)) & 0xFFFFFFFFFFFFFFFF
 
     def step(self, real: torch.Tensor, z: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Run one G/D step on ``real`` [B,C,IH,IW] (cuda).  Returns the device tensor
