@@ -101,7 +101,8 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
   const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
   const unsigned lane16 = (unsigned)lane * 16u;
   constexpr int S = VG_CH_MLP_STAGES;
-  const int ntiles = (a.units + 7) >> 3;
+  const int upw = a.upw;  // 16-row units (= active waves) of a workgroup tile
+  const int ntiles = (a.units + upw - 1) / upw;
   const int g = lane >> 4, li = lane & 15;
   const int cg = ((g & 1) << 4) + ((g & 2) << 2);  // first of the lane's 8 consecutive columns inside a tile pair, after the swap
 
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
 
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int nact = min(8, a.units - 8 * tile);
-    const bool active = wid < nact;  // wave-uniform; an idle wave still loads its share of every stage and multiplies zeros
-    const int row = (8 * tile + (active ? wid : 0)) * 16 + li;  // this lane's row
+    const int nact = min(upw, a.units - upw * tile);
+    const bool active = wid < nact;  // wave-uniform; a wave without rows still loads its share of every stage and meets every barrier
+    const int row = (upw * tile + (active ? wid : 0)) * 16 + li;  // this lane's row
 
     auto issue = [&](int s) {  // this wave's three 1-KiB pieces of stage s -> slot s % NS
       const char* src = img + (size_t)s * VG_CH_STAGE + 3072 * wid;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
         const unsigned long long t0 = __builtin_readcyclecounter();
         if (lane == 0) *(unsigned long long*)(smem + CH_RING + CH_PAR + (wid * 104 + 2 * s_idx) * 8) = t0;
       }
-      if (ahead >= 3) { if (early) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+      if (ahead >= 3) { if (early || !active) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }  // (a wave without rows stores nothing)
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       ++s_idx;
     };
     // N-major stage [64 n][192 k] (fragment f = 4 ss + jj: consecutive MFMAs go to different accumulators): acc1[jj] += W1 frag x A[6 U + ss]
-    auto stage_n = [&acc1, &F, &A, &cur, &nxt](auto u_c) {
+    auto stage_n = [&acc1, &F, &A, &cur, &nxt, active](auto u_c) {
       constexpr int U = decltype(u_c)::value;
+      if (!active) return;  // a wave without rows only carries its share of the weight stream (stage_top)
 #pragma unroll
       for (int f = 0; f < 24; ++f) {
         constexpr int dummy = 0; (void)dummy;
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       }
     };
     // K-major stage [384 n][32 k] (fragment f = n-tile): acc2[f] += W2 frag x hid; `hook(f)` runs VALU work under the MFMAs
-    auto stage_k = [&acc2, &F, &cur, &nxt](const u32x4& hf, auto&& hook) {
+    auto stage_k = [&acc2, &F, &cur, &nxt, active](const u32x4& hf, auto&& hook) {
+      if (!active) return;
 #pragma unroll
       for (int f = 0; f < 24; ++f) {
         const int fa = f + CH_LA;
@@ -241,13 +244,15 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
 
     // ---- W1(0), its GELU (exposed once) ----
     stage_top(true);
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < CH_LA; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(F[q]) : "v"(cur), "n"(q * 1024) : "memory");
+      for (int q = 0; q < CH_LA; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(F[q]) : "v"(cur), "n"(q * 1024) : "memory");
+    }
     stage_n(std::integral_constant<int, 0>{});
     stage_top(true);
     stage_n(std::integral_constant<int, 1>{});
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results, before the VALU reads them
-    {
+    if (active) {
       constexpr std::integral_constant<int, 0> c0; constexpr std::integral_constant<int, 1> c1;
       constexpr std::integral_constant<int, 2> c2; constexpr std::integral_constant<int, 3> c3;
       bias_req(c0); bias_req(c1);
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       asm volatile("" : "+s"(e.res), "+s"(e.Y), "+s"(e.Yn), "+s"(e.mean_out), "+s"(e.rstd_out));
       const int eg = ln >> 4;
       const int ecg = ((eg & 1) << 4) + ((eg & 2) << 2);
-      const int erow = (8 * tile + wid) * 16 + (ln & 15);
+      const int erow = (e.upw * tile + wid) * 16 + (ln & 15);
       const unsigned char* par = smem + CH_RING;
       const unsigned dthr = e.drop_thresh, dkey = vg_drop_key(e.drop_key, e.drop_step);
       const float dscale = e.drop_scale;
@@ -439,7 +444,11 @@ int vg_chain_mlp_fwd_launch(const VgChainMlpArgs& a0, hipStream_t st) {
   if (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta)) return -1;
   if ((long long)a.M * (a.drop_row_mul > 1 ? a.drop_row_mul : 1) * VG_CH_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
   a.units = a.M / 16;
-  const int ntiles = (a.units + 7) / 8;
+  // units per workgroup tile = active waves: as few as fill the chip's 256 CUs once (a small problem is one or two waves per
+  // workgroup, the other waves only carry their share of the weight stream), at most the 8 waves a CU's registers hold
+  a.upw = (a.units + 255) / 256;
+  if (a.upw > 8) a.upw = 8;
+  const int ntiles = (a.units + a.upw - 1) / a.upw;
   const int grid = ntiles < 256 ? ntiles : 256;
   hipLaunchKernelGGL(vg_chain_mlp_fwd_kernel, dim3(grid), dim3(512), 0, st, a);
   const hipError_t e = hipGetLastError();

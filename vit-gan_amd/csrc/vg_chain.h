@@ -26,7 +26,7 @@ struct VgChainMlpArgs {
   bf16* a1; unsigned char* z8;     // [M, 768] gelu(fc1), and gelu'(fc1 pre-activation) as byte codes (vg_g8_pack4)
   bf16* Y;                         // [M, 384] res + drop(fc2(a1))
   bf16* Yn; float* mean_out; float* rstd_out; const float* gamma; const float* beta; float eps;  // LayerNorm of Y (Yn nullable)
-  int M, units;                    // units = M / 16
+  int M, units, upw;               // units = M / 16; upw: units (active waves) per workgroup tile (both filled by the launcher)
   unsigned drop_thresh, drop_key; float drop_scale; const unsigned* drop_step; int drop_row_mul;
   unsigned long long* stamps;      // diagnostic builds only (CH_DBG & 64): [workgroup][wave][2 * stages + 2] s_memtime stamps
 };
