@@ -111,6 +111,27 @@ int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const
                            const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
                            float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
 
+/* The same entry points for another embedding width (round 4; E = 384 or 512 - C4's width; anything else returns -3, and
+ * vg_row_pack_elems_e -2): every [M, 384] operand above is [M, E], packed images are [K/32][E][32], partial rows 3 E (+ 64) wide.
+ * E = 768 (C5) does not fit the kernel's LDS ring (one 32-deep stage of W alone is 48 KiB) and stays on vg_linear_* + vg_layernorm_*. */
+long long vg_row_pack_elems_e(int E, int K); /* host only */
+int vg_row_pack_weight_e(int E, const void* W, int ld, int K, int transposed, void* Wp, void* stream);
+int vg_linear_ln_fwd_e(int E, const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
+                       float* rstd, const float* gamma, const float* beta, int M, int K, float eps, float drop_p,
+                       unsigned long long seed, int site, const unsigned* step_dev, void* stream);
+int vg_linear_dgrad_ln_bwd_e(int E, const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
+                             const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
+                             float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
+int vg_linear_sln_fwd_e(int E, const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
+                        void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
+                        const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,
+                        int site, const unsigned* step_dev, void* stream);
+int vg_linear_dgrad_sln_bwd_e(int E, const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
+                              const float* mean, const float* rstd, const float* lw, const float* lb, const float* gs,
+                              const float* bs, const void* gres, void* dh, void* dhm, float* dw_acc, int dw_accumulate,
+                              float* part, int M, int K, float drop_p, unsigned long long seed, int site,
+                              const unsigned* step_dev, void* stream);
+
 /* The MLP half of an encoder block as ONE launch (csrc/chain.hip; E = 384, hidden 768):
  *   a1 = gelu(xn W1^T + b1);  Y = res + drop(a1 W2^T + b2);  Yn = LayerNorm(Y) * gamma + beta, mean / rstd of Y   (Yn NULL: Y only)
  * replaces fc1 -> nn.GELU -> fc2 -> dropout -> residual add of src/v2/modules.py:181-182 and the LayerNorm that reads the sum

@@ -18,7 +18,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 BF_TOL = 2.0 ** -7
-E = 384
+E = 384  # set per test by the `width` fixture below
+
+
+@pytest.fixture(params=[384, 512], autouse=True)
+def width(request):
+    """Every test of this file runs at both embedding widths the kernel is built for: 384 (C1-C3; the entry points without suffix)
+    and 512 (C4; the `_e` entry points that take the width, round 4) - 4 n-tiles per wave, tiles of at most 6 m-tiles, 32 lanes per
+    row in the backward epilogue, the three column sums folded one after the other."""
+    global E
+    E = request.param
+    yield
+    E = 384
 
 
 def _u():
@@ -26,13 +37,21 @@ def _u():
     return gpu_util
 
 
+def _rcall(u, name, *args):
+    """row-kernel entry point at the current width"""
+    if E == 384:
+        u.call(name, *args)
+    else:
+        u.call(name + "_e", E, *args)
+
+
 def _pack(u, W, K, transposed):
     L = u._lib.lib()
-    n = L.vg_row_pack_elems(K)
+    n = L.vg_row_pack_elems(K) if E == 384 else L.vg_row_pack_elems_e(E, K)
     assert n == E * K
     Wp = torch.empty(n, dtype=u.BF, device="cuda")
     dW = u.dev(W, u.BF)
-    u.call("vg_row_pack_weight", u.ptr(dW), W.shape[1], K, 1 if transposed else 0, u.ptr(Wp), u.stream())
+    _rcall(u, "vg_row_pack_weight", u.ptr(dW), W.shape[1], K, 1 if transposed else 0, u.ptr(Wp), u.stream())
     return Wp
 
 
@@ -74,7 +93,7 @@ def test_linear_ln_fwd(M, K, drop):
     Yn = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
     mean = torch.empty(M, device="cuda")
     rstd = torch.empty(M, device="cuda")
-    u.call("vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(dg), u.ptr(dbt),
+    _rcall(u, "vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(dg), u.ptr(dbt),
            M, K, 1e-5, drop, seed, site, None, u.stream())
     u.sync()
     u.assert_close(Y[:M], y, BF_TOL, "Y")
@@ -89,7 +108,7 @@ def test_linear_ln_fwd(M, K, drop):
     assert bool((Y[M:] == 7.0).all()) and bool((Yn[M:] == 7.0).all()), "rows beyond M were written"
     # without a LayerNorm behind it (the last block's fc2)
     Y2 = torch.empty(M, E, dtype=u.BF, device="cuda")
-    u.call("vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y2), None, None, None, None, None,
+    _rcall(u, "vg_linear_ln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), u.ptr(dR), u.ptr(Y2), None, None, None, None, None,
            M, K, 1e-5, drop, seed, site, None, u.stream())
     u.sync()
     assert torch.equal(Y2, Y[:M])
@@ -125,7 +144,7 @@ def test_linear_dgrad_ln_bwd(M, K, drop):
     out = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
     outm = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
     part = torch.full((nparts + 1, 3 * E), 7.0, device="cuda")
-    u.call("vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out),
+    _rcall(u, "vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out),
            u.ptr(outm) if drop else None, u.ptr(part), M, K, drop, seed, site, None, u.stream())
     u.sync()
     u.assert_close(out[:M], dx, BF_TOL * 1.5, "dx")  # one ulp of the bf16 d x_hat on top of the output rounding
@@ -142,7 +161,7 @@ def test_linear_dgrad_ln_bwd(M, K, drop):
     # bitwise repeatable (no atomics, fixed fold order)
     out2 = torch.empty_like(out)
     part2 = torch.empty_like(part)
-    u.call("vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out2),
+    _rcall(u, "vg_linear_dgrad_ln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_x), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_gam), u.ptr(d_gres), u.ptr(out2),
            None, u.ptr(part2), M, K, 0.0, seed, site, None, u.stream())
     u.sync()
     assert torch.equal(out2[:M], out[:M]) and torch.equal(part2[:nparts, :2 * E], part[:nparts, :2 * E])
@@ -151,6 +170,13 @@ def test_linear_dgrad_ln_bwd(M, K, drop):
 def test_row_kernel_rejects_unsupported_shapes():
     u = _u()
     L = u._lib.lib()
+    if E != 384:
+        assert L.vg_row_pack_elems_e(E, 48) == -2 and L.vg_row_pack_elems_e(768, 768) == -2 and L.vg_row_pack_elems_e(E, 1024) == E * 1024
+        a = torch.zeros(128, 768, dtype=u.BF, device="cuda")
+        rc = L.vg_linear_ln_fwd_e(768, a.data_ptr(), a.data_ptr(), None, None, a.data_ptr(), None, None, None, None, None, 128, 768, 1e-5, 0.0, 0, 0, None,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == -3  # E = 768 does not fit the kernel's LDS ring
+        return
     assert L.vg_row_parts(130) == 0 and L.vg_row_parts(8) == 0 and L.vg_row_parts(16) == 1 and L.vg_row_parts(33280) == 256
     assert L.vg_row_pack_elems(48) == -2
     a = torch.zeros(130, 384, dtype=u.BF, device="cuda")
@@ -174,7 +200,7 @@ def test_row_kernel_race_screen(M, K):
     outs = []
     for i in range(40):
         Y = torch.empty(M, E, dtype=u.BF, device="cuda")
-        u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), None, u.ptr(R), u.ptr(Y), None, None, None, None, None, M, K, 1e-5, 0.0, 0, 0, None, u.stream())
+        _rcall(u, "vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), None, u.ptr(R), u.ptr(Y), None, None, None, None, None, M, K, 1e-5, 0.0, 0, 0, None, u.stream())
         outs.append(Y)
     u.sync()
     for i in range(1, 40):
@@ -203,11 +229,11 @@ def test_rows_do_not_depend_on_the_tile_they_land_in(K):
     for M in (Ms, 16640, Mbig):
         Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
         mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
-        u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
+        _rcall(u, "vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
                M, K, 1e-5, 0.1, 3, 1, None, u.stream())
         dx = torch.empty(M, E, dtype=u.BF, device="cuda"); dxm = torch.empty_like(dx)
         part = torch.empty(L.vg_row_parts(M), 3 * E, device="cuda")
-        u.call("vg_linear_dgrad_ln_bwd", u.ptr(A), u.ptr(WpT), u.ptr(X), u.ptr(mu), u.ptr(rs), u.ptr(gam), u.ptr(R), u.ptr(dx), u.ptr(dxm), u.ptr(part),
+        _rcall(u, "vg_linear_dgrad_ln_bwd", u.ptr(A), u.ptr(WpT), u.ptr(X), u.ptr(mu), u.ptr(rs), u.ptr(gam), u.ptr(R), u.ptr(dx), u.ptr(dxm), u.ptr(part),
                M, K, 0.1, 3, 1, None, u.stream())
         u.sync()
         outs.append([t[:Ms].clone() for t in (Y, Yn, mean, rstd, dx, dxm)])
@@ -232,7 +258,7 @@ def test_fused_forward_is_bit_identical_to_the_unfused_pair(M, K):
     Wp = _pack(u, W.float().cpu(), K, False)
     Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
     mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
-    u.call("vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
+    _rcall(u, "vg_linear_ln_fwd", u.ptr(A), u.ptr(Wp), u.ptr(b), u.ptr(R), u.ptr(Y), u.ptr(Yn), u.ptr(mean), u.ptr(rstd), u.ptr(gam), u.ptr(bet),
            M, K, 1e-5, 0.0, 0, 0, None, u.stream())
     Y2 = torch.empty_like(Y); Yn2 = torch.empty_like(Y); mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd)
     u.call("vg_linear_fwd", u.ptr(A), u.ptr(W), u.ptr(b), u.ptr(R), u.ptr(Y2), None, None, M, E, K, 0, 0.0, u.stream())
@@ -268,7 +294,7 @@ def test_linear_sln_fwd(M, K, table):
     dA, db, dR, dtab, dwm, dlw, dlb, dsc = u.dev(A, u.BF), u.dev(b), u.dev(R, u.BF), u.dev(tab), u.dev(wmod, u.BF), u.dev(lw), u.dev(lb), u.dev(sc)
     Y = torch.empty(M, E, dtype=u.BF, device="cuda"); Yn = torch.empty_like(Y)
     mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
-    u.call("vg_linear_sln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), None if table else u.ptr(dR), u.ptr(dtab) if table else None, T, u.ptr(Y), u.ptr(Yn),
+    _rcall(u, "vg_linear_sln_fwd", u.ptr(dA), u.ptr(Wp), u.ptr(db), None if table else u.ptr(dR), u.ptr(dtab) if table else None, T, u.ptr(Y), u.ptr(Yn),
            u.ptr(mean), u.ptr(rstd), u.ptr(dwm), u.ptr(dlw), u.ptr(dlb), u.ptr(dsc), C.c_void_p(dsc.data_ptr() + 4), M, K, 1e-5, drop, seed, site, None, u.stream())
     u.sync()
     u.assert_close(Y, y, BF_TOL, "Y")
@@ -316,7 +342,7 @@ def test_linear_dgrad_sln_bwd(M, K, bcast, acc):
     out = torch.empty(M, E, dtype=u.BF, device="cuda"); outm = torch.empty_like(out)
     dwa = u.dev(dw0.clone())
     part = torch.full((nparts + 1, PW), 7.0, device="cuda")
-    u.call("vg_linear_dgrad_sln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_h), bcast, u.ptr(d_wm), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_lw), u.ptr(d_lb),
+    _rcall(u, "vg_linear_dgrad_sln_bwd", u.ptr(d_dY), u.ptr(WpT), u.ptr(d_h), bcast, u.ptr(d_wm), u.ptr(d_mu), u.ptr(d_rs), u.ptr(d_lw), u.ptr(d_lb),
            u.ptr(d_sc), C.c_void_p(d_sc.data_ptr() + 4), u.ptr(d_gres), u.ptr(out), u.ptr(outm), u.ptr(dwa), acc, u.ptr(part), M, K, drop, seed, site, None, u.stream())
     u.sync()
     u.assert_close(out, dx, BF_TOL * 1.5, "dh")

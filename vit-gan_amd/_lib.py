@@ -80,6 +80,12 @@ _SIGNATURES = {
     "vg_row_parts": (c_int, [c_int]),
     "vg_linear_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_dgrad_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_row_pack_elems_e": (c_ll, [c_int, c_int]),
+    "vg_row_pack_weight_e": (c_int, [c_int, P, c_int, c_int, c_int, P, P]),
+    "vg_linear_ln_fwd_e": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_dgrad_ln_bwd_e": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_sln_fwd_e": (c_int, [c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_linear_dgrad_sln_bwd_e": (c_int, [c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_encoder_mlp_image_elems": (c_ll, []),
     "vg_encoder_mlp_pack": (c_int, [P, P, P, P]),
     "vg_encoder_mlp_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),

@@ -124,13 +124,19 @@ extern "C" int vg_dropout_apply(const void* x, void* y, long long n, float p, un
                                  step_dev, (hipStream_t)stream);
 }
 // ---- full-row Linear + LayerNorm (gemm_row.hip) ----
-extern "C" long long vg_row_pack_elems(int K) { return (K < 32 || (K & 31)) ? -2 : (long long)VG_ROW_N * K; }
-extern "C" int vg_row_pack_weight(const void* W, int ld, int K, int transposed, void* Wp, void* stream) {
+extern "C" long long vg_row_pack_elems_e(int E, int K) { return (!vg_row_width_ok(E) || K < 32 || (K & 31)) ? -2 : (long long)E * K; }
+extern "C" long long vg_row_pack_elems(int K) { return vg_row_pack_elems_e(VG_ROW_N, K); }
+extern "C" int vg_row_pack_weight_e(int E, const void* W, int ld, int K, int transposed, void* Wp, void* stream) {
   if (!W || !Wp) return -1;
+  if (!vg_row_width_ok(E)) return -3;
   VgPackJobs pj;
+  pj.N = E;
   pj.src = (const bf16*)W; pj.dst = (bf16*)Wp; pj.src_stride = 0; pj.dst_stride = 0; pj.nblocks = 1; pj.n = 1;
   pj.d[0] = {0, 0, K, ld, transposed ? 1 : 0};
   return vg_pack_rows_launch(pj, (hipStream_t)stream);
+}
+extern "C" int vg_row_pack_weight(const void* W, int ld, int K, int transposed, void* Wp, void* stream) {
+  return vg_row_pack_weight_e(VG_ROW_N, W, ld, K, transposed, Wp, stream);
 }
 extern "C" int vg_row_parts(int M) { return vg_row_nwg(M); }
 static void row_drop(VgRowArgs& ra, float p, unsigned long long seed, int site, const unsigned* step_dev) {
@@ -138,16 +144,23 @@ static void row_drop(VgRowArgs& ra, float p, unsigned long long seed, int site, 
   if (!t) return;
   ra.drop_thresh = (unsigned)t; ra.drop_key = vg_site_key(seed, site); ra.drop_scale = 256.f / (256.f - t); ra.drop_step = step_dev;
 }
-extern "C" int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
+extern "C" int vg_linear_ln_fwd_e(int E, const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
                                 float* rstd, const float* gamma, const float* beta, int M, int K, float eps, float drop_p,
                                 unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  if (!vg_row_width_ok(E)) return -3;
   if (!A || !Wp || !Y || (Yn && (!mean || !rstd || !gamma || !beta)) || drop_p < 0.f || drop_p >= 1.f) return -1;
   VgRowArgs ra = {};
+  ra.N = E;
   ra.A = (const bf16*)A; ra.lda = K; ra.Wp = (const bf16*)Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = (const bf16*)res;
   ra.Y = (bf16*)Y; ra.Yn = (bf16*)Yn; ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = eps;
   row_drop(ra, drop_p, seed, site, step_dev);
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
+extern "C" int vg_linear_ln_fwd(const void* A, const void* Wp, const float* bias, const void* res, void* Y, void* Yn, float* mean,
+                                float* rstd, const float* gamma, const float* beta, int M, int K, float eps, float drop_p,
+                                unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  return vg_linear_ln_fwd_e(VG_ROW_N, A, Wp, bias, res, Y, Yn, mean, rstd, gamma, beta, M, K, eps, drop_p, seed, site, step_dev, stream);
 }
 extern "C" long long vg_encoder_mlp_image_elems(void) { return (long long)VG_CH_MLP_STAGES * VG_CH_STAGE / 2; }
 extern "C" int vg_encoder_mlp_pack(const void* W1, const void* W2, void* img, void* stream) {
@@ -167,13 +180,15 @@ extern "C" int vg_encoder_mlp_fwd(const void* xn, const void* img, const float* 
   const int r = vg_chain_mlp_fwd_launch(ca, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
-extern "C" int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
+extern "C" int vg_linear_sln_fwd_e(int E, const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
                                  void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
                                  const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,
                                  int site, const unsigned* step_dev, void* stream) {
+  if (!vg_row_width_ok(E)) return -3;
   if (!A || !Wp || !Y || !Yn || !mean || !rstd || !wmod || !lw || !lb || !gs || !bs || drop_p < 0.f || drop_p >= 1.f) return -1;
   if (res && resf) return -1;
   VgRowArgs ra = {};
+  ra.N = E;
   ra.A = (const bf16*)A; ra.lda = K; ra.Wp = (const bf16*)Wp; ra.M = M; ra.K = K; ra.bias = bias; ra.res = (const bf16*)res;
   ra.resf = resf; ra.res_period = res_period;
   ra.Y = (bf16*)Y; ra.Yn = (bf16*)Yn; ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = lw; ra.beta = lb; ra.eps = eps;
@@ -182,14 +197,22 @@ extern "C" int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bia
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNFWD, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
-extern "C" int vg_linear_dgrad_sln_bwd(const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
+extern "C" int vg_linear_sln_fwd(const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
+                                 void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
+                                 const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,
+                                 int site, const unsigned* step_dev, void* stream) {
+  return vg_linear_sln_fwd_e(VG_ROW_N, A, Wp, bias, res, resf, res_period, Y, Yn, mean, rstd, wmod, lw, lb, gs, bs, M, K, eps, drop_p, seed, site, step_dev, stream);
+}
+extern "C" int vg_linear_dgrad_sln_bwd_e(int E, const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
                                        const float* mean, const float* rstd, const float* lw, const float* lb, const float* gs,
                                        const float* bs, const void* gres, void* dh, void* dhm, float* dw_acc, int dw_accumulate,
                                        float* part, int M, int K, float drop_p, unsigned long long seed, int site,
                                        const unsigned* step_dev, void* stream) {
+  if (!vg_row_width_ok(E)) return -3;
   if (!dY || !WpT || !h || !wmod || !mean || !rstd || !lw || !lb || !gs || !bs || !dh || !dw_acc || !part || drop_p < 0.f || drop_p >= 1.f)
     return -1;
   VgRowArgs ra = {};
+  ra.N = E;
   ra.A = (const bf16*)dY; ra.lda = K; ra.Wp = (const bf16*)WpT; ra.M = M; ra.K = K; ra.x = (const bf16*)h; ra.x_period = h_bcast_rows;
   ra.mean = mean; ra.rstd = rstd; ra.gamma = lw; ra.lbias = lb; ra.gs = gs; ra.bs = bs; ra.wmod = (const bf16*)wmod;
   ra.gres = (const bf16*)gres; ra.dx = (bf16*)dh; ra.dxm = (bf16*)dhm; ra.dw_acc = dw_acc; ra.dw_accumulate = dw_accumulate; ra.part = part;
@@ -198,17 +221,31 @@ extern "C" int vg_linear_dgrad_sln_bwd(const void* dY, const void* WpT, const vo
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
-extern "C" int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
+extern "C" int vg_linear_dgrad_sln_bwd(const void* dY, const void* WpT, const void* h, int h_bcast_rows, const void* wmod,
+                                       const float* mean, const float* rstd, const float* lw, const float* lb, const float* gs,
+                                       const float* bs, const void* gres, void* dh, void* dhm, float* dw_acc, int dw_accumulate,
+                                       float* part, int M, int K, float drop_p, unsigned long long seed, int site,
+                                       const unsigned* step_dev, void* stream) {
+  return vg_linear_dgrad_sln_bwd_e(VG_ROW_N, dY, WpT, h, h_bcast_rows, wmod, mean, rstd, lw, lb, gs, bs, gres, dh, dhm, dw_acc, dw_accumulate, part, M, K, drop_p, seed, site, step_dev, stream);
+}
+extern "C" int vg_linear_dgrad_ln_bwd_e(int E, const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
                                       const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
                                       float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  if (!vg_row_width_ok(E)) return -3;
   if (!dY || !WpT || !x || !mean || !rstd || !gamma || !dx || !part || drop_p < 0.f || drop_p >= 1.f) return -1;
   VgRowArgs ra = {};
+  ra.N = E;
   ra.A = (const bf16*)dY; ra.lda = K; ra.Wp = (const bf16*)WpT; ra.M = M; ra.K = K; ra.x = (const bf16*)x; ra.mean = mean; ra.rstd = rstd;
   ra.gamma = gamma; ra.gres = (const bf16*)gres; ra.dx = (bf16*)dx; ra.dxm = (bf16*)dxm; ra.part = part;
   if (dxm) row_drop(ra, drop_p, seed, site, step_dev);
   if (dxm && !ra.drop_thresh) { ra.drop_thresh = 0; ra.drop_scale = 1.f; }
   const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
+extern "C" int vg_linear_dgrad_ln_bwd(const void* dY, const void* WpT, const void* x, const float* mean, const float* rstd,
+                                      const float* gamma, const void* gres, void* dx, void* dxm, float* part, int M, int K,
+                                      float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream) {
+  return vg_linear_dgrad_ln_bwd_e(VG_ROW_N, dY, WpT, x, mean, rstd, gamma, gres, dx, dxm, part, M, K, drop_p, seed, site, step_dev, stream);
 }
 extern "C" int vg_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int S, int HE, float scale, void* stream) {
   if (!qkv || !out || !lse) return -1;

@@ -236,7 +236,7 @@ struct VitWs {
 };
 // The full-row GEMMs (LayerNorm in the epilogue) take the block Linears whose output is the embedding when E = 384 and the
 // rows come in whole units of 16; their workgroup count is also the number of LayerNorm-backward partial rows.
-static inline int vit_row_nwg(const VgVitDims& d, int M) { return d.E == VG_ROW_N ? vg_row_nwg(M) : 0; }
+static inline int vit_row_nwg(const VgVitDims& d, int M) { return vg_row_width_ok(d.E) ? vg_row_nwg(M) : 0; }  // (E = 384, and 512 since round 4)
 static long long carve_vit(const VgVitDims& d, int B, void* base, VitWs& w) {
   const long long E = d.E, NP = (long long)(d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = (long long)B * S;
   const long long Kp = (long long)d.C * d.P * d.P, L = d.L, rE = (long long)d.R * E;
@@ -339,6 +339,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   const long long po_wo = 0, po_w2 = po_wo + (long long)E * E, po_wqkvT = po_w2 + (long long)E * rE, po_w1T = po_wqkvT + 3LL * E * E;
   if (rown) {
     VgPackJobs pj;
+    pj.N = E;
     pj.src = Pb + lay.layer0; pj.dst = w.wpack; pj.src_stride = lay.layer_stride; pj.dst_stride = lay.layer_weights; pj.nblocks = d.L; pj.n = 4;
     pj.d[0] = {lay.wo, po_wo, E, E, 0};          // out-projection forward: W [E, E], contraction E
     pj.d[1] = {lay.w2, po_w2, rE, rE, 0};        // fc2 forward: W [E, rE], contraction rE
@@ -349,6 +350,7 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   auto row_fwd = [&](const bf16* A, int K, const bf16* Wp, const float* bias, const bf16* res, bf16* Y, bf16* Yn, float* mean,
                      float* rstd, const float* gamma, const float* beta, int site, int rows = 0, int drm = 1, long long ldr = 0) -> int {
     VgRowArgs ra = {};
+    ra.N = E;
     ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.bias = bias; ra.res = res; ra.ldr = ldr; ra.Y = Y; ra.Yn = Yn;
     ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = gamma; ra.beta = beta; ra.eps = 1e-5f; ra.drop_row_mul = drm;
     if (dr.thr) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
@@ -460,6 +462,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma,
                      const bf16* gres, bf16* dx, bf16* dxm, float* part, int site, int rows = 0, int drm = 1) -> int {
     VgRowArgs ra = {};
+    ra.N = E;
     ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
     ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = want_wgrad ? part : nullptr; ra.drop_row_mul = drm;  // (no parameter gradients wanted: no column sums)
     if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
@@ -741,7 +744,7 @@ struct GenWs {
   bf16 *pdqkv, *pgm1, *pgm2;  // per-block copies of the weight-gradient dY operands (dropout on): two blocks' weight gradients go out as one launch
 };
 // generator rows R = B*T: the full-row kernels (SLN in the epilogue) take the Linears whose output is the embedding when E = 384
-static inline int gen_row_nwg(const VgGenDims& d, int R) { return (d.E == VG_ROW_N && d.O % 64 == 0 && d.O >= 128) ? vg_row_nwg(R) : 0; }
+static inline int gen_row_nwg(const VgGenDims& d, int R) { return (vg_row_width_ok(d.E) && d.O % 64 == 0 && d.O >= 128) ? vg_row_nwg(R) : 0; }
 static inline long long gen_pack_block(const VgGenDims& d) { return 6LL * d.E * d.E; }  // E*E + E*E + 3E*E + E*E
 static long long carve_gen(const VgGenDims& d, int B, void* base, GenWs& w) {
   const long long E = d.E, T = d.T, R = (long long)B * T, L = d.L;
@@ -828,6 +831,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   const long long pb = gen_pack_block(d), po_wo = 0, po_wm = (long long)E * E, po_wqkvT = 2LL * E * E, po_wmT = 5LL * E * E;
   if (rown) {
     VgPackJobs pj;
+    pj.N = E;
     pj.src = Pb + lay.layer0; pj.dst = w.wpack; pj.src_stride = lay.layer_stride; pj.dst_stride = pb; pj.nblocks = d.L; pj.n = 4;
     pj.d[0] = {lay.wo, po_wo, E, E, 0};           // output_linear forward
     pj.d[1] = {lay.wm, po_wm, E, E, 0};           // block MLP forward
@@ -835,6 +839,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
     pj.d[3] = {lay.wm, po_wmT, E, E, 1};          // block MLP input gradient
     VG_TRY(vg_pack_rows_launch(pj, st));
     VgPackJobs ph;                                // first SIREN layer's input gradient: s1_w [O, E] read transposed
+    ph.N = E;
     ph.src = Pb + lay.s1_w; ph.dst = w.wpack + (long long)d.L * pb; ph.src_stride = 0; ph.dst_stride = 0; ph.nblocks = 1; ph.n = 1;
     ph.d[0] = {0, 0, d.O, E, 1};
     VG_TRY(vg_pack_rows_launch(ph, st));
@@ -843,6 +848,7 @@ extern "C" int vg_gen_forward(const VgGenNet* net, int B, const float* z, void* 
   auto row_fwd = [&](const bf16* A, const bf16* Wp, const float* bias, const bf16* res, const float* resf, bf16* Y, bf16* Yn, float* mean,
                      float* rstd, const float* lw, const float* lb, const float* sc, int site) -> int {
     VgRowArgs ra = {};
+    ra.N = E;
     ra.A = A; ra.lda = E; ra.Wp = Wp; ra.M = R; ra.K = E; ra.bias = bias; ra.res = res; ra.resf = resf; ra.res_period = T; ra.Y = Y; ra.Yn = Yn;
     ra.mean_out = mean; ra.rstd_out = rstd; ra.gamma = lw; ra.beta = lb; ra.eps = 1e-5f; ra.wmod = w.wmod; ra.gs = sc; ra.bs = sc + 1;
     if (dr.thr) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
@@ -936,6 +942,7 @@ extern "C" int vg_gen_backward_stages(const VgGenNet* net, int B, void* ws, cons
   auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* hx, int hbc, const float* mean, const float* rstd, const float* lw,
                      const float* lb, const float* sc, const bf16* gres, bf16* dh, bf16* dhm, int accumulate, float* part, int site) -> int {
     VgRowArgs ra = {};
+    ra.N = E;
     ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = R; ra.K = K; ra.x = hx; ra.x_period = hbc; ra.mean = mean; ra.rstd = rstd; ra.gamma = lw; ra.lbias = lb;
     ra.gs = sc; ra.bs = sc + 1; ra.wmod = w.wmod; ra.gres = gres; ra.dx = dh; ra.dxm = dhm; ra.dw_acc = w.dw_acc; ra.dw_accumulate = accumulate;
     ra.part = part;

@@ -36,23 +36,34 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int RW_E = VG_ROW_N;
-constexpr int RW_WIMG = RW_E * 64;                     // one W stage image: 384 rows x 64 B
 #ifndef RW_MAXMT_
 #define RW_MAXMT_ 9
 #endif
-constexpr int RW_MAXMT = RW_MAXMT_;  // m-tiles per tile (tuning builds: make var DEFS=-DRW_MAXMT_=5)
-constexpr int RW_STAGE = RW_WIMG + RW_MAXMT * 1024;    // + A stage image: 16 MT rows x 64 B
 constexpr int RW_NSLOT = 4;
-constexpr int RW_RING = RW_NSLOT * RW_STAGE;           // 135 168 B
-constexpr int RW_RED = (3 * 32 * RW_E + 16) * 4;        // LNBWD column-sum fold: [3 sums][32 row-group slots][384] fp32 (+ the SLN scalars), over the ring
-constexpr int RW_BODY = RW_RED > RW_RING ? RW_RED : RW_RING;
-constexpr int RW_GAM = 2 * RW_E * 4;                   // behind both: gamma (and the SLN's bias) in fp32 - the LNBWD epilogue has no registers for them
-constexpr int RW_TS = 784;                             // row stride of the bf16 epilogue tile (LNBWD): 768 + 16 (ds_write_b64 2-way at worst)
-constexpr int RW_TSF = 1552;                           // row stride of the fp32 epilogue tile (LNFWD, 80 rows at a time): 1536 + 16
-static_assert(RW_MAXMT * 16 * RW_TS <= RW_RING, "epilogue tile must fit the ring");
-static_assert(80 * RW_TSF <= RW_RING, "fp32 half tile must fit the ring");
-static_assert(RW_BODY + RW_GAM <= 160 * 1024, "LDS");
+// Everything that depends on the output width N (= the embedding width: 384 for C1-C3, 512 for C4; round 4).  8 waves side by side own
+// N / 8 columns each = NT MFMA n-tiles; the accumulators (4 NT MT registers) cap the tile height: 9 m-tiles at NT = 3, 6 at NT = 4.
+// N = 768 (C5) does not fit: one 32-deep W stage is 48 KiB, a ring of 3 with its A stages and the LayerNorm vectors 162 KiB.
+template <int N> struct RwCfg {
+  static_assert(N == 384 || N == 512, "widths this kernel is built for");
+  static constexpr int NT = N / 128;                      // n-tiles per wave
+  static constexpr int WIMG = N * 64;                     // one W stage image: N rows x 64 B
+  static constexpr int MAXMT = N == 384 ? RW_MAXMT_ : 6;  // m-tiles per tile (tuning builds: make var DEFS=-DRW_MAXMT_=5)
+  static constexpr int STAGE = WIMG + MAXMT * 1024;       // + A stage image: 16 MT rows x 64 B
+  static constexpr int RING = RW_NSLOT * STAGE;           // 135 168 B / 155 648 B
+  // LNBWD column-sum fold over the ring: [3 sums][32 row-group slots][N] fp32 (+ the SLN scalars) at once where it fits (N = 384:
+  // round 3's fold, its association unchanged), one sum at a time otherwise
+  static constexpr bool FOLD3 = (3 * 32 * N + 16) * 4 <= 160 * 1024 - 2 * N * 4;
+  static constexpr int RED = ((FOLD3 ? 3 : 1) * 32 * N + 16) * 4;
+  static constexpr int BODY = RED > RING ? RED : RING;
+  static constexpr int GAM = 2 * N * 4;                   // behind both: gamma (and the SLN's bias) in fp32 - the LNBWD epilogue has no registers for them
+  static constexpr int TS = 2 * N + 16;                   // row stride of the bf16 epilogue tile (LNBWD): + 16 (ds_write_b64 2-way at worst)
+  static constexpr int TSF = 4 * N + 16;                  // row stride of the fp32 epilogue tile (LNFWD, HM m-tiles at a time)
+  static constexpr int HM = N == 384 ? 5 : 4;
+  static constexpr int CPL = N / 128;                     // chunks per lane and row of the row-wise epilogue passes (128 columns per round of the lanes)
+  static_assert(MAXMT * 16 * TS <= RING, "epilogue tile must fit the ring");
+  static_assert(HM * 16 * TSF <= RING, "fp32 half tile must fit the ring");
+  static_assert(BODY + GAM <= 160 * 1024, "LDS");
+};
 
 // row-form chunk swizzle of gemm.hip: 16-B chunk c of row r lives at position c ^ {0,2,3,1}[(r>>2)&3]
 __device__ __host__ __forceinline__ int rw_row_f(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
@@ -66,6 +77,7 @@ __device__ __forceinline__ void rw_wait_vm(int n) {  // n is wave-uniform (scala
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -87,9 +99,12 @@ __device__ __forceinline__ float rw_row16_sum(float v) {
 #else
 #define RW_DBG(bit) 0
 #endif
-template <int EPI, bool SLN>
+template <int EPI, bool SLN, int N>
 __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_BODY + RW_GAM];
+  using Cf = RwCfg<N>;
+  constexpr int RW_E = N, NT = Cf::NT, RW_WIMG = Cf::WIMG, RW_MAXMT = Cf::MAXMT, RW_STAGE = Cf::STAGE, RW_BODY = Cf::BODY, RW_TS = Cf::TS,
+                RW_TSF = Cf::TSF, CPL = Cf::CPL;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RW_BODY + Cf::GAM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wid >> 2;  // the two waves of a SIMD are w and w + 4
@@ -99,9 +114,16 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
   const long long a8 = (long long)128 * a.lda * 2;  // bytes from piece 0 to piece 8
 
+  // N = 512, forward: gamma / beta live behind the ring too - 64 registers of them on top of 4 chunks of residual, modulation and row values
+  // spilled 92 registers in the self-modulated form
+  constexpr bool GB_LDS = N > 384;
   if (EPI == VG_ROW_LNBWD && tid < RW_E / 4) {  // visible to everyone behind the first tile's barriers
     *(f32x4*)(smem + RW_BODY + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
     if (SLN) *(f32x4*)(smem + RW_BODY + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.lbias + 4 * tid);
+  }
+  if (EPI == VG_ROW_LNFWD && GB_LDS && a.Yn && tid < RW_E / 4) {
+    *(f32x4*)(smem + RW_BODY + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
+    *(f32x4*)(smem + RW_BODY + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.beta + 4 * tid);
   }
   float cum_s = 0.f;               // LNBWD + SLN: threads 0 / 1 carry d gs / d bs
   float cum[3] = {0.f, 0.f, 0.f};  // LNBWD: this thread's columns tid, tid + 512, tid + 1024 of the workgroup's partial row
@@ -114,13 +136,13 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     asm volatile("" : "+v"(lnm));
     // fragment addresses inside a stage: W rows 48 wid + 16 nt + li, A rows 16 mt + li; the swizzle only sees li
     const unsigned fsw = (unsigned)((((lnm >> 4) ^ rw_row_f(lnm & 15))) << 4);
-    const unsigned fw = sbase + (unsigned)((48 * wid + (lnm & 15)) * 64) + fsw;     // n-tile nt at + 1024 nt
+    const unsigned fw = sbase + (unsigned)((16 * NT * wid + (lnm & 15)) * 64) + fsw;  // n-tile nt at + 1024 nt
     const unsigned fa = sbase + (unsigned)(RW_WIMG + (lnm & 15) * 64) + fsw;        // m-tile mt at + 1024 mt
     // LDS-DMA lane offsets: W pieces are contiguous; an A piece is 16 rows x 64 B, position lane&3 of row lane>>2 holds
     // chunk (lane&3) ^ f(row)
     const unsigned offW = (unsigned)lnm * 16u;
     const unsigned offA = ((unsigned)(lnm >> 2) * (unsigned)a.lda + (unsigned)(((lnm & 3) ^ rw_row_f(lnm >> 2)) << 3)) * 2u;
-    const int pps = 3 + (wid < MT ? 1 : 0) + ((MT == 9 && wid == 0) ? 1 : 0);  // LDS-DMA pieces of this wave per stage
+    const int pps = NT + (wid < MT ? 1 : 0) + ((MT == 9 && wid == 0) ? 1 : 0);  // LDS-DMA pieces of this wave per stage
     const char* wptr = (const char*)a.Wp + 1024 * wid;
     const char* aptr = (const char*)a.A + ((long long)(m0 + 16 * wid) * a.lda) * 2;
     auto issue = [&](int slot) {
@@ -132,31 +154,32 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #else
       const char* wsrc = wptr; const char* asrc = aptr;
 #endif
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + offW), (lptr_t)d, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 8192 + offW), (lptr_t)(d + 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 16384 + offW), (lptr_t)(d + 16384), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)  // piece wid + 8 i of the W stage's 8 NT contiguous 1-KiB pieces
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 8192 * i + offW), (lptr_t)(d + 8192 * i), 16, 0, 0);
       if (wid < MT) __builtin_amdgcn_global_load_lds((gptr_t)(asrc + offA), (lptr_t)(d + RW_WIMG), 16, 0, 0);
       if (MT == 9 && wid == 0) __builtin_amdgcn_global_load_lds((gptr_t)(asrc + a8 + offA), (lptr_t)(d + RW_WIMG + 8192), 16, 0, 0);
       wptr += RW_WIMG; aptr += 64;
     };
-    struct Frags { u32x4 w[3]; u32x4 m[MT]; };
+    struct Frags { u32x4 w[NT]; u32x4 m[MT]; };
     auto read_frags = [&](Frags& f, int slot) {
       const unsigned so = (unsigned)(slot * RW_STAGE);
       const unsigned w0 = fw + so, a0 = fa + so;
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.w[nt]) : "v"(w0), "n"(1024 * nt) : "memory");
+      for (int nt = 0; nt < NT; ++nt) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.w[nt]) : "v"(w0), "n"(1024 * nt) : "memory");
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.m[mt]) : "v"(a0), "n"(1024 * mt) : "memory");
     };
     auto wait_frags = [&](Frags& f) {  // the registers are tied behind the wait: no use of them can be scheduled above it
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2])::"memory");
+      if (NT > 3) asm volatile("" : "+v"(f.w[NT - 1])::"memory");
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(f.m[mt])::"memory");
     };
 
-    f32x4 acc[3][MT];
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -187,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fm[mt] = __builtin_bit_cast(bf16x8, cur.m[mt]);
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const bf16x8 fn = __builtin_bit_cast(bf16x8, cur.w[nt]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = vg_mfma(fn, fm[mt], acc[nt][mt]);
@@ -229,26 +252,26 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     if (EPI == VG_ROW_LNFWD) {
       // LNFWD keeps the sum in fp32 until the residual is added (ONE rounding, as the unfused epilogue had): fp32 tile rows of
       // 1552 B, 5 m-tiles (80 rows) at a time
-      constexpr int HM = 5, NH = (MT + HM - 1) / HM;
+      constexpr int HM = Cf::HM, NH = (MT + HM - 1) / HM;
       const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(a.drop_key, a.drop_step);
       const float dscale = a.drop_scale;
       const unsigned drm = a.drop_row_mul > 1 ? (unsigned)a.drop_row_mul : 1u;
       const size_t ldres = a.ldr > 0 ? (size_t)a.ldr : (size_t)RW_E;
-      f32x4 b4[3];
+      f32x4 b4[NT];
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         b4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (e.bias) b4[nt] = *(const f32x4*)(e.bias + 48 * wid + 16 * nt + 4 * g);
+        if (e.bias) b4[nt] = *(const f32x4*)(e.bias + 16 * NT * wid + 16 * nt + 4 * g);
       }
-      float gam[3][8], bet[3][8];
-      if (e.Yn) {
+      float gam[GB_LDS ? 1 : CPL][8], bet[GB_LDS ? 1 : CPL][8];
+      if (e.Yn && !GB_LDS) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < CPL; ++i) {
           const int c = 8 * (sub + 16 * i);
           const f32x4 g0 = *(const f32x4*)(e.gamma + c), g1 = *(const f32x4*)(e.gamma + c + 4);
           const f32x4 b0 = *(const f32x4*)(e.beta + c), b1 = *(const f32x4*)(e.beta + c + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { gam[i][j] = g0[j]; gam[i][j + 4] = g1[j]; bet[i][j] = b0[j]; bet[i][j + 4] = b1[j]; }
+          for (int j = 0; j < 4; ++j) { gam[GB_LDS ? 0 : i][j] = g0[j]; gam[GB_LDS ? 0 : i][j + 4] = g1[j]; bet[GB_LDS ? 0 : i][j] = b0[j]; bet[GB_LDS ? 0 : i][j + 4] = b1[j]; }
         }
       }
 #pragma unroll
@@ -258,13 +281,13 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         const int hm = (MT - mt0) < HM ? (MT - mt0) : HM;  // m-tiles of this half (compile-time after unrolling)
         const int rows = 16 * hm, passes = (rows + 31) / 32;
         // residual rows of pass 0 (phase-2 layout): in flight across the dump
-        bf16x8 rn[3];  // residual rows of the NEXT pass
-        bf16x8 wn[SLN ? 3 : 1];  // SLN: modulation rows of the next pass
-        auto ld_res = [&](bf16x8 (&dst)[3], int ps) {
+        bf16x8 rn[CPL];  // residual rows of the NEXT pass
+        bf16x8 wn[SLN ? CPL : 1];  // SLN: modulation rows of the next pass
+        auto ld_res = [&](bf16x8 (&dst)[CPL], int ps) {
           const int rl = 32 * ps + 4 * wid + rg;
           const size_t row = (size_t)(m0 + 16 * mt0 + (rl < rows ? rl : 0));
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
+          for (int i = 0; i < CPL; ++i) {
             dst[i] = (bf16x8){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (e.res && !RW_DBG(32)) dst[i] = *(const bf16x8*)(e.res + row * ldres + 8 * (sub + 16 * i));
             if (SLN) wn[SLN ? i : 0] = *(const bf16x8*)(e.wmod + row * RW_E + 8 * (sub + 16 * i));
@@ -276,8 +299,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         for (int mt = 0; mt < HM; ++mt) {
           if (mt0 + mt < MT) {
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-              const int n = 48 * wid + 16 * nt + 4 * g;
+            for (int nt = 0; nt < NT; ++nt) {
+              const int n = 16 * NT * wid + 16 * nt + 4 * g;
               f32x4 v = acc[nt][mt0 + mt < MT ? mt0 + mt : 0] + b4[nt];
               if (dthr) {
                 const unsigned wd = vg_drop_word(dkey, ((unsigned)(m0 + 16 * (mt0 + mt) + li) * drm * (unsigned)RW_E + (unsigned)n) >> 2);
@@ -293,17 +316,17 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         for (int ps = 0; ps < passes; ++ps) {
           {
             const int rem = rows - 32 * ps;  // 16 or >= 32: with 16 only waves 0..3 have rows
-            bf16x8 rc[3] = {rn[0], rn[1], rn[2]};
-            bf16x8 wc[SLN ? 3 : 1];
-            if (SLN) { wc[0] = wn[0]; wc[SLN ? 1 : 0] = wn[SLN ? 1 : 0]; wc[SLN ? 2 : 0] = wn[SLN ? 2 : 0]; }
+            bf16x8 rc[CPL], wc[SLN ? CPL : 1];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { rc[i] = rn[i]; if (SLN) wc[SLN ? i : 0] = wn[SLN ? i : 0]; }
             if (ps + 1 < passes) ld_res(rn, ps + 1);
             if (rem >= 32 || wid < 4) {
               const int rl = 32 * ps + 4 * wid + rg;
               const size_t row = (size_t)(m0 + 16 * mt0 + rl);
-              float v[3][8];
+              float v[CPL][8];
               float sm = 0.f;
 #pragma unroll
-              for (int i = 0; i < 3; ++i) {
+              for (int i = 0; i < CPL; ++i) {
                 const f32x4 t0 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i));
                 const f32x4 t1 = *(const f32x4*)(smem + rl * RW_TSF + 32 * (sub + 16 * i) + 16);
                 bf16x8 o;
@@ -327,17 +350,25 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
                 const float mu = rw_row16_sum(sm) * (1.0f / RW_E);
                 float q = 0.f;
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < CPL; ++i)
 #pragma unroll
                   for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mu; q += c * c; }  // unfused, as norm.hip's build has it
                 const float rs = rsqrtf(fmaf(rw_row16_sum(q), 1.0f / RW_E, a.eps));  // norm.hip's contracted form: bit-identical statistics
                 if (sub == 0) { e.mean_out[row] = mu; e.rstd_out[row] = rs; }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < CPL; ++i) {
                   bf16x8 o;
+                  float gl[8], bl[8];
+                  if (GB_LDS) {
+                    const unsigned char* gp = smem + RW_BODY + 32 * (sub + 16 * i);
+                    const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 16);
+                    const f32x4 b0 = *(const f32x4*)(gp + RW_E * 4), b1 = *(const f32x4*)(gp + RW_E * 4 + 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gl[j] = g0[j]; gl[j + 4] = g1[j]; bl[j] = b0[j]; bl[j + 4] = b1[j]; }
+                  }
 #pragma unroll
                   for (int j = 0; j < 8; ++j) {
-                    float r = fmaf((v[i][j] - mu) * rs, gam[i][j], bet[i][j]);
+                    float r = fmaf((v[i][j] - mu) * rs, GB_LDS ? gl[j] : gam[GB_LDS ? 0 : i][j], GB_LDS ? bl[j] : bet[GB_LDS ? 0 : i][j]);
                     if (SLN) r = vg_bf2f(wc[SLN ? i : 0][j]) * fmaf(g_s, r, b_s);
                     o[j] = vg_f2bf(r);
                   }
@@ -351,7 +382,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     } else {
       // LPR lanes per row: 16 (16-byte chunks, 4 rows per wave and pass) for the plain LayerNorm; 32 (8-byte chunks, 2 rows) for the
       // self-modulated one, whose extra operands (w, d w, the LayerNorm's bias) would not leave room for 72 column accumulators
-      constexpr int LPR = SLN ? 32 : 16, CH = 128 / LPR, RPW = 64 / LPR, RPP = 8 * RPW;
+      // (N = 512: 32 lanes per row for the plain LayerNorm too - 16 lanes would hold 96 column accumulators)
+      constexpr int LPR = (SLN || N > 384) ? 32 : 16, CH = 128 / LPR, RPW = 64 / LPR, RPP = 8 * RPW;
       constexpr int ROWS = 16 * MT, PASSES = (ROWS + RPP - 1) / RPP;
       typedef typename std::conditional<CH == 8, bf16x8, bf16x4>::type chunk_t;
       const int subl = ln % LPR, rgl = ln / LPR;
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       const unsigned drm = a.drop_row_mul > 1 ? (unsigned)a.drop_row_mul : 1u;
       auto zero_chunk = [] { chunk_t z; for (int j = 0; j < CH; ++j) z[j] = (bf16)0.f; return z; };
       auto row_sum = [&](float v) { v = rw_row16_sum(v); if (LPR == 32) v += __shfl_xor(v, 16, 64); return v; };
-      chunk_t xn[3];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
+      chunk_t xn[CPL];  // x rows and statistics of the NEXT pass: in flight while the current pass is computed
       float mun, rsn;
       auto ld_ops = [&](int ps) {
         const int rl = RPP * ps + RPW * wid + rgl;
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
         const size_t xrow = a.x_period > 0 ? (size_t)((int)(row % (size_t)a.x_period)) : row;  // x broadcast over the batch (generator block 0)
         mun = e.mean[row]; rsn = e.rstd[row];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < CPL; ++i) {
           xn[i] = zero_chunk();
           if (!RW_DBG(16)) xn[i] = *(const chunk_t*)(e.x + xrow * RW_E + CH * (subl + LPR * i));
         }
@@ -377,17 +409,17 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const f32x4 v = acc[nt][mt];
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = vg_f2bf(v[r]);
-          *(bf16x4*)(smem + (16 * mt + li) * RW_TS + (48 * wid + 16 * nt + 4 * g) * 2) = o;
+          *(bf16x4*)(smem + (16 * mt + li) * RW_TS + (16 * NT * wid + 16 * nt + 4 * g) * 2) = o;
         }
       __syncthreads();
-      float ag[3][CH], ab[3][CH], ac[3][CH];
+      float ag[CPL][CH], ab[CPL][CH], ac[CPL][CH];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < CPL; ++i)
 #pragma unroll
         for (int j = 0; j < CH; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ac[i][j] = 0.f; }
       const unsigned char* gam_lds = smem + RW_BODY;
@@ -405,24 +437,26 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 #pragma unroll 1
       for (int ps = 0; ps < PASSES; ++ps) {
         const int rem = ROWS - RPP * ps;  // LPR 16: 16 or >= 32 - with 16 only waves 0..3 have rows; LPR 32: always a whole pass
-        chunk_t xc[3] = {xn[0], xn[1], xn[2]};
+        chunk_t xc[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) xc[i] = xn[i];
         const float mu = mun, rs = rsn;
         if (ps + 1 < PASSES) ld_ops(ps + 1);
         if (rem >= RPP || wid < 4) {
           const int rl = RPP * ps + RPW * wid + rgl;
           const size_t row = (size_t)(m0 + rl);
-          chunk_t gr[3];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
-          chunk_t wm[SLN ? 3 : 1];
+          chunk_t gr[CPL];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
+          chunk_t wm[SLN ? CPL : 1];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
+          for (int i = 0; i < CPL; ++i) {
             if (SLN) wm[SLN ? i : 0] = *(const chunk_t*)(e.wmod + row * RW_E + CH * (subl + LPR * i));
             gr[i] = zero_chunk();
             if (e.gres && !RW_DBG(16)) gr[i] = *(const chunk_t*)(e.gres + row * RW_E + CH * (subl + LPR * i));
           }
-          float xh[3][CH], gg[3][CH];
+          float xh[CPL][CH], gg[CPL][CH];
           float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
+          for (int i = 0; i < CPL; ++i) {
             const chunk_t t = *(const chunk_t*)(smem + rl * RW_TS + 2 * CH * (subl + LPR * i));
             float gm[CH], lb[SLN ? CH : 1], dwv[SLN ? CH : 1];
             ld_f32(gam_lds, i, gm);
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           c1 = row_sum(c1) * (1.0f / RW_E);
           c2 = row_sum(c2) * (1.0f / RW_E);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
+          for (int i = 0; i < CPL; ++i) {
             const int c = CH * (subl + LPR * i);
             chunk_t o;
 #pragma unroll
@@ -489,45 +523,58 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       // done with) and 3 x 384 threads add the 8 RPW rows of a column in a fixed order.  (The first version reduced the row groups of
       // a wave with __shfl_xor first: 432 ds_bpermute + lgkmcnt round trips per wave, a visible part of this epilogue.)
       __syncthreads();  // the tile has been read
-      float* red = (float*)smem;  // [3][NSL][384] (+ 16 scalars)
+      float* red = (float*)smem;  // [3 or 1][NSL][N] (+ 16 scalars)
       constexpr int NSL = 8 * RPW;
-      if (sums) {
-        const int slot = RPW * wid + rgl;
+      constexpr int NSUM = Cf::FOLD3 ? 3 : 1;  // sums folded per round (N = 512: the three sums take the region one after the other)
+      const int slot = RPW * wid + rgl;
+      auto put = [&](int which, int at) {  // this row group's partial row of sum `which` -> region `at`
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < CPL; ++i) {
           const int col = CH * (subl + LPR * i);
 #pragma unroll
           for (int q = 0; q < CH / 4; ++q) {
-            *(f32x4*)(red + (0 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ag[i][4 * q], ag[i][4 * q + 1], ag[i][4 * q + 2], ag[i][4 * q + 3]};
-            *(f32x4*)(red + (1 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ab[i][4 * q], ab[i][4 * q + 1], ab[i][4 * q + 2], ab[i][4 * q + 3]};
-            *(f32x4*)(red + (2 * NSL + slot) * RW_E + col + 4 * q) = (f32x4){ac[i][4 * q], ac[i][4 * q + 1], ac[i][4 * q + 2], ac[i][4 * q + 3]};
+            const float (&src)[CPL][CH] = which == 0 ? ag : (which == 1 ? ab : ac);
+            *(f32x4*)(red + (at * NSL + slot) * RW_E + col + 4 * q) = (f32x4){src[i][4 * q], src[i][4 * q + 1], src[i][4 * q + 2], src[i][4 * q + 3]};
           }
         }
-      }
+      };
+      auto fold_col = [&](const float* r0) {  // a wave's row groups first, then the waves pairwise: fixed association
+        float t8[8];
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {
+          float t = r0[(RPW * w8) * RW_E];
+#pragma unroll
+          for (int r = 1; r < RPW; ++r) t += r0[(RPW * w8 + r) * RW_E];
+          t8[w8] = t;
+        }
+        return ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+      };
       if (SLN) {  // the two scalars: wave sums behind the column sums' region
         const float a_ = vg_wave_sum(s_gs), b_ = vg_wave_sum(s_bs);
-        if (lane == 0) { red[3 * NSL * RW_E + 2 * wid] = a_; red[3 * NSL * RW_E + 2 * wid + 1] = b_; }
+        if (lane == 0) { red[NSUM * NSL * RW_E + 2 * wid] = a_; red[NSUM * NSL * RW_E + 2 * wid + 1] = b_; }
       }
-      __syncthreads();
+      if (Cf::FOLD3) {
+        if (sums) { put(0, 0); put(1, 1); put(2, 2); }
+        __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int c = tid + 512 * k;
-        if (sums && c < 3 * RW_E) {
-          const int which = c / RW_E, col = c - which * RW_E;
-          const float* r0 = red + (which * NSL) * RW_E + col;
-          float t8[8];
-#pragma unroll
-          for (int w8 = 0; w8 < 8; ++w8) {  // a wave's row groups first, then the waves pairwise: fixed association
-            float t = r0[(RPW * w8) * RW_E];
-#pragma unroll
-            for (int r = 1; r < RPW; ++r) t += r0[(RPW * w8 + r) * RW_E];
-            t8[w8] = t;
+        for (int k = 0; k < 3; ++k) {
+          const int c = tid + 512 * k;
+          if (sums && c < 3 * RW_E) {
+            const int which = c / RW_E, col = c - which * RW_E;
+            cum[k] += fold_col(red + (which * NSL) * RW_E + col);
           }
-          cum[k] += ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+        }
+      } else {  // RW_E == 512 threads: thread tid folds column tid of sum k, cum[k] <-> column tid + 512 k of the partial row as above
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (k > 0) __syncthreads();  // the previous sum has been folded
+          if (sums) put(k, 0);
+          __syncthreads();
+          if (sums && tid < RW_E) cum[k] += fold_col(red + tid);
         }
       }
       if (SLN && tid < 2) {
-        const float* r0 = red + 3 * NSL * RW_E + tid;
+        const float* r0 = red + NSUM * NSL * RW_E + tid;
         cum_s += ((r0[0] + r0[2]) + (r0[4] + r0[6])) + ((r0[8] + r0[10]) + (r0[12] + r0[14]));
       }
     }
@@ -546,9 +593,13 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
       case 4: tile(std::integral_constant<int, 4>{}, m0); break;
       case 5: tile(std::integral_constant<int, 5>{}, m0); break;
       case 6: tile(std::integral_constant<int, 6>{}, m0); break;
-      case 7: tile(std::integral_constant<int, 7>{}, m0); break;
-      case 8: tile(std::integral_constant<int, 8>{}, m0); break;
-      default: tile(std::integral_constant<int, 9>{}, m0); break;
+      default:
+        if constexpr (RW_MAXMT > 6) {  // (the taller tiles exist at N = 384 only: 4 NT MT accumulator registers)
+          if (mt == 7) tile(std::integral_constant<int, 7>{}, m0);
+          else if (mt == 8) tile(std::integral_constant<int, 8>{}, m0);
+          else tile(std::integral_constant<int, RW_MAXMT>{}, m0);
+        }
+        break;
     }
     n -= mt; m0 += 16 * mt; first = false;
   }
@@ -565,16 +616,17 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
 
 // ---- weight packing -----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vg_pack_rows_kernel(const VgPackJobs J) {
+  const int NW = J.N;  // output width of the packed problems: rows of a stage image
   long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk of the block's packed area
   int q = 0;
   for (; q < J.n; ++q) {
-    const long long chunks = (long long)RW_E * J.d[q].K / 8;
+    const long long chunks = (long long)NW * J.d[q].K / 8;
     if (t < chunks) break;
     t -= chunks;
   }
   if (q >= J.n) return;
   const VgPackDesc& D = J.d[q];
-  const int s = (int)(t / (RW_E * 4)), rem = (int)(t - (long long)s * (RW_E * 4));
+  const int s = (int)(t / (NW * 4)), rem = (int)(t - (long long)s * (NW * 4));
   const int n = rem >> 2, pc = rem & 3, c = pc ^ rw_row_f(n), k = 32 * s + 8 * c;
   const bf16* src = J.src + (long long)blockIdx.y * J.src_stride + D.src_off;
   bf16* dst = J.dst + (long long)blockIdx.y * J.dst_stride + D.dst_off + t * 8;
@@ -588,13 +640,17 @@ __global__ __launch_bounds__(256) void vg_pack_rows_kernel(const VgPackJobs J) {
   *(bf16x8*)dst = v;
 }
 
-int vg_pack_rows_launch(const VgPackJobs& jobs, hipStream_t st) {
-  if (jobs.n < 1 || jobs.n > 4 || jobs.nblocks < 1 || !jobs.src || !jobs.dst) return -1;
+int vg_row_width_ok(int N) { return N == 384 || N == 512; }
+
+int vg_pack_rows_launch(const VgPackJobs& jobs0, hipStream_t st) {
+  VgPackJobs jobs = jobs0;
+  if (jobs.N == 0) jobs.N = VG_ROW_N;
+  if (jobs.n < 1 || jobs.n > 4 || jobs.nblocks < 1 || !jobs.src || !jobs.dst || !vg_row_width_ok(jobs.N)) return -1;
   long long chunks = 0;
   for (int i = 0; i < jobs.n; ++i) {
     const VgPackDesc& d = jobs.d[i];
     if (d.K < 32 || (d.K & 31) || (d.ld & 7) || (d.src_off & 7) || (d.dst_off & 7)) return -3;
-    chunks += (long long)RW_E * d.K / 8;
+    chunks += (long long)jobs.N * d.K / 8;
   }
   if ((jobs.src_stride & 7) || (jobs.dst_stride & 7)) return -3;
   hipLaunchKernelGGL(vg_pack_rows_kernel, dim3((unsigned)((chunks + 255) / 256), jobs.nblocks), dim3(256), 0, st, jobs);
@@ -614,9 +670,26 @@ int vg_row_nwg(int M) {
   return want < 256 ? want : 256;
 }
 
+template <int N>
+static int rw_launch(VgRowArgs a, int epi, hipStream_t st) {
+  const int nwg = a.nwg;
+  const bool sln = a.wmod != nullptr;
+  if (epi == VG_ROW_LNFWD) {
+    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, true, N>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, false, N>), dim3(nwg), dim3(512), 0, st, a);
+  } else {
+    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, true, N>), dim3(nwg), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, false, N>), dim3(nwg), dim3(512), 0, st, a);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 1 : -(int)e;
+}
+
 int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
+  if (a.N == 0) a.N = VG_ROW_N;
+  const int RW_E = a.N;
   const int nwg = vg_row_nwg(a.M);
-  if (!nwg || a.K < 128 || (a.K & 63) || (a.lda & 7) || (a.ldr & 7) || !a.A || !a.Wp) return 0;
+  if (!vg_row_width_ok(a.N) || !nwg || a.K < 128 || (a.K & 63) || (a.lda & 7) || (a.ldr & 7) || !a.A || !a.Wp) return 0;
   if ((long long)a.M * (a.drop_row_mul > 1 ? a.drop_row_mul : 1) * RW_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
   a.units = a.M / 16;
   a.nwg = nwg;
@@ -629,16 +702,11 @@ int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
   if (epi == VG_ROW_LNFWD) {
     if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta)) || (sln && !a.Yn)) return -1;
     if (a.resf && (a.res || a.res_period < 1)) return -1;
-    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, true>), dim3(nwg), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, false>), dim3(nwg), dim3(512), 0, st, a);
   } else if (epi == VG_ROW_LNBWD) {
     if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || (sln && (!a.part || !a.lbias || !a.dw_acc))) return -1;  // part == nullptr: no column sums (input gradient only)
     a.part_w = 3 * RW_E + (sln ? 64 : 0);
-    if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, true>), dim3(nwg), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, false>), dim3(nwg), dim3(512), 0, st, a);
   } else {
     return -4;
   }
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 1 : -(int)e;
+  return a.N == 512 ? rw_launch<512>(a, epi, st) : rw_launch<384>(a, epi, st);
 }

@@ -3,14 +3,16 @@
 #pragma once
 #include "vg_common.h"
 
-#define VG_ROW_N 384  // output width of every full-row problem (the embedding width of the C1-C3 configurations)
+#define VG_ROW_N 384  // default output width of a full-row problem (the embedding width of the C1-C3 configurations); 512 (C4) since round 4
+int vg_row_width_ok(int N);  // widths the kernel is built for: 384, 512
 
 enum { VG_ROW_LNFWD = 0, VG_ROW_LNBWD = 1 };
 
 struct VgRowArgs {
   const bf16* A; int lda;  // [M, K] row-major
-  const bf16* Wp;          // packed weights: [K/32][384][32] stage images (vg_pack_rows_launch)
+  const bf16* Wp;          // packed weights: [K/32][N][32] stage images (vg_pack_rows_launch)
   int M, K;                // M % 16 == 0, K % 64 == 0
+  int N;                   // output width = row length of every [M, N] operand below: 384 or 512 (0 = 384)
   int units, nwg;          // 16-row units of A; workgroups (filled by the launcher)
   int dbg;                 // diagnostic builds only (VG_TUNING)
   // ---- VG_ROW_LNFWD:  y = res + drop(A W^T + bias);  yn = LN(y) * gamma + beta ------------------------------------
@@ -57,6 +59,7 @@ struct VgPackJobs {
   const bf16* src; bf16* dst;
   long long src_stride, dst_stride;  // elements between blocks
   int nblocks, n;
+  int N;                             // output width of the packed problems (rows of a stage image): 384 or 512 (0 = 384)
   VgPackDesc d[4];
 };
 int vg_pack_rows_launch(const VgPackJobs& jobs, hipStream_t st);
