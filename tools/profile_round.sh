@@ -33,5 +33,7 @@ python3 tools/step_timeline.py $OUT/ks_default > $OUT/${TAG}_step_timeline.txt 2
 f=$(find $OUT/ks_gp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_gp_step_kernel_stats.csv
 (python3 tools/micro/blas_cmp.py; python3 tools/gemm_bench.py) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_vendor_gemm_calibration_raw.txt
 python3 -m pytest tests/test_blocks_gpu.py -m gpu -q -s 2>&1 | grep -E "tensors checked|SLN scalars|^ +(sln|transformer_layers|layer_norm)" > $OUT/stage_raw.txt
+# the bench line quotes the two PMC summaries from profiles/ (when their tree hash is this tree's): put this run's there first
+cp $OUT/${TAG}_gemm_pmc_traffic.json $OUT/${TAG}_step_pmc_summary.json $R/profiles/ 2>/dev/null
 python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
 tail -4 $OUT/traffic.txt; tail -12 $OUT/summary.txt; grep -v amdgpu.ids $OUT/${TAG}_gemm_bench.txt; cut -c1-400 $OUT/${TAG}_bench_line.json
