@@ -145,6 +145,21 @@ int vg_encoder_mlp_fwd(const void* xn, const void* img, const float* b1, const f
                        void* Y, void* Yn, float* mean, float* rstd, const float* gamma, const float* beta, int M, float eps,
                        float drop_p, unsigned long long seed, int site, const unsigned* step_dev, void* stream);
 
+/* Everything of an encoder block BETWEEN its attention and the next block's, but for the QKV projection, as ONE launch (csrc/chain.hip, the MLP
+ * chain with the out-projection in front):
+ *   x_mid = x + drop_a(ao Wo^T + bo);  xn2 = LayerNorm2(x_mid);  a1 = gelu(xn2 W1^T + b1);  Y = x_mid + drop_m(a1 W2^T + b2);  Yn = LayerNorm(Y)
+ * replaces out_projection + dropout1 + residual, norm2, fc1, nn.GELU, fc2 + dropout2 + residual (src/v2/modules.py:179-182) and the next block's
+ * norm1 (:168).  x_mid, xn2 (+ mean2 / rstd2), a1, dcode, Y, Yn (+ mean / rstd) are written for the backward; none is read back.
+ * img = vg_encoder_post_attention_pack(Wo [384,384], W1 [768,384], W2 [384,768]).  M % 16 == 0.  An operator with its tests and measurements
+ * (DESIGN.md s3); the engine does not call it. */
+long long vg_encoder_post_attention_image_elems(void); /* host only */
+int vg_encoder_post_attention_pack(const void* Wo, const void* W1, const void* W2, void* img, void* stream);
+int vg_encoder_post_attention_fwd(const void* ao, const void* x, const void* img, const float* bo, const float* b1, const float* b2,
+                                  const float* gamma2, const float* beta2, const float* gamma, const float* beta, void* xmid, void* xn2,
+                                  float* mean2, float* rstd2, void* a1, void* dcode, void* Y, void* Yn, float* mean, float* rstd, int M,
+                                  float eps, float drop_p, unsigned long long seed, int site_attn, int site_mlp,
+                                  const unsigned* step_dev, void* stream);
+
 /* The same two kernels with the v1 generator's self-modulated LayerNorm (src/v1/spectral_layer_norm.py:19-20) in the epilogue:
  * vg_linear_sln_fwd:  Y = (res | resf[row % res_period]) + drop(A Wp^T + bias);  Yn = w * (gs * (LN(Y) * lw + lb) + bs)
  *   replaces output_linear / the block MLP + dropout + residual + the SLN that reads the sum (src/v1/transformer.py:85-88);

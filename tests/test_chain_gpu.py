@@ -130,3 +130,88 @@ def test_encoder_mlp_fwd_rows_do_not_depend_on_their_tile():
         outs.append((A1[:M1].clone(), Z8[:M1].clone(), Y[:M1].clone(), Yn[:M1].clone(), mean[:M1].clone(), rstd[:M1].clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _mask_site(u, M, p, seed, site):
+    return _mask(u, M, p, seed, site)
+
+
+@pytest.mark.parametrize("M", [16, 128, 144, 2080, 16640, 32768, 33280])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_encoder_post_attention_fwd(M, drop):
+    """vg_encoder_post_attention_fwd: out-projection + dropout + residual, norm2, fc1, GELU, fc2 + dropout + residual and the next norm1 in one
+    launch (src/v2/modules.py:179-182, :168), every stored tensor against fp32 PyTorch with bf16 roundings where the kernel stores."""
+    u = _u()
+    g = torch.Generator().manual_seed(M + 11)
+    ao = u.rbf(torch.randn(M, E, generator=g))
+    x = u.rbf(torch.randn(M, E, generator=g))
+    Wo = u.rbf(torch.randn(E, E, generator=g) / math.sqrt(E))
+    bo = torch.randn(E, generator=g) * 0.1
+    W1 = u.rbf(torch.randn(HID, E, generator=g) / math.sqrt(E))
+    b1 = torch.randn(HID, generator=g) * 0.1
+    W2 = u.rbf(torch.randn(E, HID, generator=g) / math.sqrt(HID))
+    b2 = torch.randn(E, generator=g) * 0.1
+    g2, be2 = 1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    gn, ben = 1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    seed, sa, sm = 17, 3, 4
+    lin = ao @ Wo.t() + bo
+    if drop:
+        lin = lin * _mask(u, M, drop, seed, sa)
+    xmid = u.rbf(lin + x)
+    xn2 = u.rbf(F.layer_norm(xmid, (E,), g2, be2, 1e-5))
+    z = xn2 @ W1.t() + b1
+    a1 = u.rbf(F.gelu(z))
+    y = a1 @ W2.t() + b2
+    if drop:
+        y = y * _mask(u, M, drop, seed, sm)
+    y = u.rbf(y + xmid)
+    yn = F.layer_norm(y, (E,), gn, ben, 1e-5)
+
+    L = u._lib.lib()
+    img = torch.empty(L.vg_encoder_post_attention_image_elems(), dtype=u.BF, device="cuda")
+    dWo, dW1, dW2 = u.dev(Wo, u.BF), u.dev(W1, u.BF), u.dev(W2, u.BF)
+    u.call("vg_encoder_post_attention_pack", u.ptr(dWo), u.ptr(dW1), u.ptr(dW2), u.ptr(img), u.stream())
+    d_ao, d_x = u.dev(ao, u.BF), u.dev(x, u.BF)
+    dv = [u.dev(t) for t in (bo, b1, b2, g2, be2, gn, ben)]
+    XM = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda"); XN = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    A1 = torch.full((M + 16, HID), 7.0, dtype=u.BF, device="cuda"); Z8 = torch.full((M + 16, HID), 9, dtype=torch.uint8, device="cuda")
+    Y = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda"); Yn = torch.full((M + 16, E), 7.0, dtype=u.BF, device="cuda")
+    m2, r2, mn, rn = (torch.empty(M, device="cuda") for _ in range(4))
+
+    def run(XM_, XN_, A1_, Z8_, Y_, Yn_):
+        u.call("vg_encoder_post_attention_fwd", u.ptr(d_ao), u.ptr(d_x), u.ptr(img), u.ptr(dv[0]), u.ptr(dv[1]), u.ptr(dv[2]), u.ptr(dv[3]), u.ptr(dv[4]),
+               u.ptr(dv[5]), u.ptr(dv[6]), u.ptr(XM_), u.ptr(XN_), u.ptr(m2), u.ptr(r2), u.ptr(A1_), u.ptr(Z8_), u.ptr(Y_), u.ptr(Yn_), u.ptr(mn), u.ptr(rn),
+               M, 1e-5, drop, seed, sa, sm, None, u.stream())
+        u.sync()
+    run(XM, XN, A1, Z8, Y, Yn)
+    u.assert_close(XM[:M], xmid, BF_TOL, "x_mid")
+    xk = XM[:M].float().cpu()
+    u.assert_close(XN[:M], F.layer_norm(xk, (E,), g2, be2, 1e-5), BF_TOL, "xn2 vs LN(own x_mid)")
+    u.assert_close(m2, xk.mean(1), 3e-5, "mean2", floor=1e-6)
+    u.assert_close(r2, 1.0 / torch.sqrt(xk.var(1, unbiased=False) + 1e-5), 3e-5, "rstd2")
+    # the MLP on the kernel's own xn2 (one flipped bf16 rounding upstream would otherwise be charged to the stages behind it)
+    xnk = XN[:M].float().cpu()
+    zk = xnk @ W1.t() + b1
+    a1k = u.rbf(F.gelu(zk))
+    u.assert_close(A1[:M], a1k, BF_TOL, "a1 vs gelu(fc1(own xn2))")
+    dz = (Z8[:M].float().cpu() - 27.0) * 0.005
+    assert float((dz - _gelu_grad(zk)).abs().max()) <= 0.0051
+    yk_ref = A1[:M].float().cpu() @ W2.t() + b2
+    if drop:
+        yk_ref = yk_ref * _mask(u, M, drop, seed, sm)
+    u.assert_close(Y[:M], u.rbf(yk_ref + xk), BF_TOL, "Y vs fc2(own a1) + own x_mid")
+    yk = Y[:M].float().cpu()
+    u.assert_close(Yn[:M], F.layer_norm(yk, (E,), gn, ben, 1e-5), BF_TOL, "Yn vs LN(own Y)")
+    u.assert_close(mn, yk.mean(1), 3e-5, "mean", floor=1e-6)
+    u.assert_close(rn, 1.0 / torch.sqrt(yk.var(1, unbiased=False) + 1e-5), 3e-5, "rstd")
+    # end to end against the reference chain (loose: three bf16 tensors deep)
+    u.assert_close(Y[:M], y, 2.0 ** -5, "Y vs reference")
+    u.assert_close(Yn[:M], yn, 2.0 ** -4, "Yn vs reference")
+    for t, fill in ((XM, 7.0), (XN, 7.0), (A1, 7.0), (Y, 7.0), (Yn, 7.0)):
+        assert bool((t[M:] == fill).all()), "rows beyond M were written"
+    assert bool((Z8[M:] == 9).all())
+    # bitwise repeatable
+    outs2 = [torch.empty_like(t) for t in (XM, XN, A1, Z8, Y, Yn)]
+    run(*outs2)
+    for a_, b_ in zip((XM, XN, A1, Z8, Y, Yn), outs2):
+        assert torch.equal(a_[:M], b_[:M])

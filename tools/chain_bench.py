@@ -70,6 +70,29 @@ for M in [int(m) for m in os.environ.get("MS", "32768,33280,16384,16640").split(
     def pair():
         fc1(); fc2()
 
+    # the chain with the out-projection + residual + norm2 in front, against its three launches
+    ao = torch.randn(M, E, device="cuda").to(BF); xin = torch.randn(M, E, device="cuda").to(BF)
+    wo = (torch.randn(E, E, device="cuda") * 0.05).to(BF); bo = torch.zeros(E, device="cuda")
+    xmid = torch.empty(M, E, device="cuda", dtype=BF); xn2 = torch.empty(M, E, device="cuda", dtype=BF)
+    m2 = torch.empty(M, device="cuda"); r2 = torch.empty(M, device="cuda")
+    img2 = torch.empty(L.vg_encoder_post_attention_image_elems(), device="cuda", dtype=BF)
+    _lib.check(L.vg_encoder_post_attention_pack(p(wo), p(w1), p(w2), p(img2), st), "pack2")
+    wop = torch.empty(E * E, device="cuda", dtype=BF)
+    _lib.check(L.vg_row_pack_weight(p(wo), E, E, 0, p(wop), st), "rowpack")
+
+    def chain2():
+        _lib.check(L.vg_encoder_post_attention_fwd(p(ao), p(xin), p(img2), p(bo), p(b1), p(b2), p(gam), p(bet), p(gam), p(bet), p(xmid), p(xn2), p(m2), p(r2),
+                                                   p(a1), p(z8), p(y), p(yn), p(mean), p(rstd), M, 1e-5, 0.1, 1, 2, 3, None, st), "chain2")
+
+    def outp():
+        _lib.check(L.vg_linear_ln_fwd(p(ao), p(wop), p(bo), p(xin), p(xmid), p(xn2), p(m2), p(r2), p(gam), p(bet), M, E, 1e-5, 0.1, 1, 2, None, st), "outp")
+
+    def triple():
+        outp(); fc1(); fc2()
+
+    t_c2, t_0 = timeit(chain2), timeit(outp)
+    b_c2, b_t = back_to_back(chain2), back_to_back(triple)
+    print(f"M={M}: out-projection + norm2 + MLP chain {t_c2:.1f} us (back to back {b_c2:.1f})   out-proj+ln {t_0:.1f} + fc1 + fc2 (three launches back to back {b_t:.1f})", flush=True)
     t_c, t_1, t_2 = timeit(chain), timeit(fc1), timeit(fc2)
     b_c, b_p = back_to_back(chain), back_to_back(pair)
     mb = M * (E * 2 * 4 + HID * 3) / 1e6

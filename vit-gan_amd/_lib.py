@@ -89,6 +89,9 @@ _SIGNATURES = {
     "vg_encoder_mlp_image_elems": (c_ll, []),
     "vg_encoder_mlp_pack": (c_int, [P, P, P, P]),
     "vg_encoder_mlp_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
+    "vg_encoder_post_attention_image_elems": (c_ll, []),
+    "vg_encoder_post_attention_pack": (c_int, [P, P, P, P, P]),
+    "vg_encoder_post_attention_fwd": (c_int, [P] * 20 + [c_int, c_float, c_float, C.c_ulonglong, c_int, c_int, P, P]),
     "vg_linear_sln_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_linear_dgrad_sln_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, C.c_ulonglong, c_int, P, P]),
     "vg_colsum_f32": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),

@@ -180,6 +180,31 @@ extern "C" int vg_encoder_mlp_fwd(const void* xn, const void* img, const float* 
   const int r = vg_chain_mlp_fwd_launch(ca, (hipStream_t)stream);
   return r > 0 ? 0 : (r < 0 ? -r : -3);
 }
+extern "C" long long vg_encoder_post_attention_image_elems(void) { return (long long)(VG_CH_MLP_STAGES + VG_CH_FRONT_STAGES) * VG_CH_STAGE / 2; }
+extern "C" int vg_encoder_post_attention_pack(const void* Wo, const void* W1, const void* W2, void* img, void* stream) {
+  return vg_chain_block_pack_launch((const bf16*)Wo, (const bf16*)W1, (const bf16*)W2, (bf16*)img, (hipStream_t)stream);
+}
+extern "C" int vg_encoder_post_attention_fwd(const void* ao, const void* x, const void* img, const float* bo, const float* b1, const float* b2,
+                                             const float* gamma2, const float* beta2, const float* gamma, const float* beta, void* xmid, void* xn2,
+                                             float* mean2, float* rstd2, void* a1, void* dcode, void* Y, void* Yn, float* mean, float* rstd, int M,
+                                             float eps, float drop_p, unsigned long long seed, int site_attn, int site_mlp,
+                                             const unsigned* step_dev, void* stream) {
+  if (!ao || !x || !img || !b1 || !b2 || !gamma2 || !beta2 || !xmid || !xn2 || !mean2 || !rstd2 || !a1 || !dcode || !Y ||
+      (Yn && (!mean || !rstd || !gamma || !beta)) || drop_p < 0.f || drop_p >= 1.f)
+    return -1;
+  VgChainMlpArgs ca = {};
+  ca.ao = (const bf16*)ao; ca.xin = (const bf16*)x; ca.ldx = VG_CH_E; ca.img = (const bf16*)img; ca.bo = bo; ca.b1 = b1; ca.b2 = b2;
+  ca.gamma2 = gamma2; ca.beta2 = beta2; ca.xmid = (bf16*)xmid; ca.xn_out = (bf16*)xn2; ca.mean2 = mean2; ca.rstd2 = rstd2;
+  ca.a1 = (bf16*)a1; ca.z8 = (unsigned char*)dcode; ca.Y = (bf16*)Y; ca.Yn = (bf16*)Yn; ca.mean_out = mean; ca.rstd_out = rstd;
+  ca.gamma = gamma; ca.beta = beta; ca.eps = eps; ca.M = M;
+  int t = (int)lrintf(drop_p * 256.f); if (t < 0) t = 0; if (t > 255) t = 255;
+  if (t) {
+    ca.drop_thresh = (unsigned)t; ca.drop_key = vg_site_key(seed, site_mlp); ca.drop_key_a = vg_site_key(seed, site_attn);
+    ca.drop_scale = 256.f / (256.f - t); ca.drop_step = step_dev;
+  }
+  const int r = vg_chain_mlp_fwd_launch(ca, (hipStream_t)stream);
+  return r > 0 ? 0 : (r < 0 ? -r : -3);
+}
 extern "C" int vg_linear_sln_fwd_e(int E, const void* A, const void* Wp, const float* bias, const void* res, const float* resf, int res_period,
                                  void* Y, void* Yn, float* mean, float* rstd, const void* wmod, const float* lw, const float* lb,
                                  const float* gs, const float* bs, int M, int K, float eps, float drop_p, unsigned long long seed,

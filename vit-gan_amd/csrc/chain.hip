@@ -5,8 +5,9 @@
 // (k loop) and the HBM phase (epilogue) run one after the other.  Here a wave owns 16 rows for the whole chain:
 // fc1's A operand (12 fragments), the 64-column slice of the hidden it is working on and fc2's 16 x 384 accumulators all
 // live in its registers; the hidden is WRITTEN (a1 and the gelu' codes, for the backward) but never read back.  Only the
-// weights move: the chain image (vg_chain.h) streams through a 6-slot LDS ring once per workgroup, one 24-KiB stage per
-// barrier, three stages of LDS-DMA in flight; a fragment read is `stage + 1024 f + 16 lane`, one per MFMA, through a
+// weights move: the chain image (vg_chain.h) streams through a 6-slot LDS ring once per workgroup tile (as many 16-row units =
+// active waves as fill the chip's 256 CUs once, at most 8; waves without rows only carry their share of the stream), one 24-KiB
+// stage per barrier, three stages of LDS-DMA in flight; a fragment read is `stage + 1024 f + 16 lane`, one per MFMA, through a
 // rolling register queue with a counted lgkmcnt - the step (wait, MFMA, next read) is one asm statement, so the schedule
 // is the source order (gemm_wr.hip's protocol).
 //
@@ -25,7 +26,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int CH_NS = 6;                       // ring slots
 constexpr int CH_RING = CH_NS * VG_CH_STAGE;   // 147 456 B
 #ifndef CH_QN_
-#define CH_QN_ 8
+#define CH_QN_ 6
 #endif
 constexpr int CH_QN = CH_QN_, CH_LA = CH_QN - 1;  // fragment queue slots / look-ahead
 static_assert(24 % CH_QN == 0, "a stage must start at queue slot 0");
@@ -34,7 +35,8 @@ static_assert(24 % CH_QN == 0, "a stage must start at queue slot 0");
 // `s_waitcnt vmcnt(0) lgkmcnt(0)`, which drains the three stages of LDS-DMA in flight and the fragment queue (first version:
 // 2.0 us per stage instead of 0.7).  A bias quad is an extra ds_read_b128 inside the counted fragment queue instead.
 constexpr int CH_PAR_B1 = 0, CH_PAR_B2 = VG_CH_HID * 4, CH_PAR_GAM = CH_PAR_B2 + VG_CH_E * 4, CH_PAR_BET = CH_PAR_GAM + VG_CH_E * 4,
-              CH_PAR = CH_PAR_BET + VG_CH_E * 4;
+              CH_PAR_BO = CH_PAR_BET + VG_CH_E * 4, CH_PAR_GAM2 = CH_PAR_BO + VG_CH_E * 4, CH_PAR_BET2 = CH_PAR_GAM2 + VG_CH_E * 4,
+              CH_PAR = CH_PAR_BET2 + VG_CH_E * 4;  // b1 | b2 | gamma | beta | (front:) bo | gamma2 | beta2
 static_assert(CH_RING + CH_PAR <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ uint32_t ch_pk(float a, float b) {
@@ -94,13 +96,17 @@ __device__ __forceinline__ void ch_gelu_both2(f32x2 x, f32x2& g, f32x2& dg) {
 #endif
 }  // namespace
 
-__global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpArgs a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_RING + CH_PAR + ((CH_DBG & 64) ? 8 * 104 * 8 : 0)];
+// FRONT: the out-projection, its dropout + residual and norm2 in front of the MLP (modules.py:179-180, :172): 12 more K-major stages
+// from the attention output's fragments, an epilogue in registers that leaves x_mid and xn2 in memory (the backward reads them)
+// and xn2 in the A fragments fc1 multiplies - k order S (vg_chain.h): the 8 consecutive columns a lane holds behind the swap.
+template <bool FRONT>
+__global__ __launch_bounds__(512) void vg_chain_fwd_kernel(const VgChainMlpArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_RING + CH_PAR + (((CH_DBG & 64) && !FRONT) ? 8 * 104 * 8 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned sbase = (unsigned)(unsigned long)(lptr_t)smem;
   const unsigned lane16 = (unsigned)lane * 16u;
-  constexpr int S = VG_CH_MLP_STAGES;
+  constexpr int S = VG_CH_MLP_STAGES + (FRONT ? VG_CH_FRONT_STAGES : 0);
   const int upw = a.upw;  // 16-row units (= active waves) of a workgroup tile
   const int ntiles = (a.units + upw - 1) / upw;
   const int g = lane >> 4, li = lane & 15;
@@ -112,16 +118,18 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
   bf16* a1p = a.a1; unsigned char* z8p = a.z8;
   asm volatile("" : "+s"(img), "+s"(b1), "+s"(b2), "+s"(a1p), "+s"(z8p));
 
-  for (int i = tid; i < CH_PAR / 16; i += 512) {  // b1 | b2 | gamma | beta
-    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (i < VG_CH_HID / 4) v = *(const f32x4*)(b1 + 4 * i);
-    else if (i < (VG_CH_HID + VG_CH_E) / 4) v = *(const f32x4*)(b2 + 4 * i - VG_CH_HID);
-    else if (a.Yn) v = i < (VG_CH_HID + 2 * VG_CH_E) / 4 ? *(const f32x4*)(a.gamma + 4 * i - VG_CH_HID - VG_CH_E)
-                                                           : *(const f32x4*)(a.beta + 4 * i - VG_CH_HID - 2 * VG_CH_E);
-    *(f32x4*)(smem + CH_RING + 16 * i) = v;
+  for (int i = tid; i < CH_PAR / 16; i += 512) {
+    const int seg = i / (VG_CH_E / 4);  // 0,1: b1; 2: b2; 3: gamma; 4: beta; 5: bo; 6: gamma2; 7: beta2
+    const float* src = seg < 2 ? b1 + 4 * i
+                     : seg == 2 ? b2 + 4 * i - VG_CH_HID
+                     : seg == 3 ? (a.Yn ? a.gamma + 4 * i - 3 * VG_CH_E : nullptr)
+                     : seg == 4 ? (a.Yn ? a.beta + 4 * i - 4 * VG_CH_E : nullptr)
+                     : !FRONT ? nullptr
+                     : seg == 5 ? (a.bo ? a.bo + 4 * i - 5 * VG_CH_E : nullptr)
+                     : seg == 6 ? a.gamma2 + 4 * i - 6 * VG_CH_E : a.beta2 + 4 * i - 7 * VG_CH_E;
+    *(f32x4*)(smem + CH_RING + 16 * i) = src ? *(const f32x4*)src : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
-  const unsigned pb1 = sbase + CH_RING + CH_PAR_B1 + 16u * (unsigned)g;  // b1[16 jj + 4 g ..] of group t at + 256 t + 64 jj
 
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -137,21 +145,20 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       for (int i = 0; i < 3; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024 * i + lane16), (lptr_t)(d + 1024 * i), 16, 0, 0);
     };
-    // fc1's A operand: rows of xn as 12 fragments, k order natural (16 B per lane and k-step); requested before the ring's
-    // first stages so that the first counted wait covers them
+    // The first Linear's A operand: rows of xn (FRONT: of the attention output) as 12 fragments, k order natural (16 B per lane and
+    // k-step); requested before the ring's first stages so that the first counted wait covers them.  FRONT: the epilogue behind
+    // the out-projection overwrites them with xn2's.
     u32x4 A[12];
 #pragma unroll
     for (int s = 0; s < 12; ++s) {
       A[s] = (u32x4){0u, 0u, 0u, 0u};
-      if (active) A[s] = *(const u32x4*)(a.xn + (size_t)row * a.ldx + 32 * s + 8 * g);
+      if (active) A[s] = *(const u32x4*)((FRONT ? a.ao : a.xn) + (size_t)row * a.ldx + 32 * s + 8 * g);
     }
 #pragma unroll
     for (int s = 0; s < CH_NS - 1; ++s) issue(s);
     f32x4 acc2[24], acc1[4];
 #pragma unroll
     for (int j = 0; j < 24; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     u32x4 hid[2][2];  // fc2's A fragments of the group in flight: [t & 1][k-step], k order P
     u32x4 F[CH_QN];
     unsigned cur = sbase + lane16 - VG_CH_STAGE, nxt = sbase + lane16;  // fragment addresses of the current / next stage
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       // pieces (vmcnt(9)) made every top wait for a stage issued 1.7 stages ago instead of 3 (+10 us per launch).
       // Behind the barrier stage s+1 is whole and nobody reads stage s-1 any more: its slot takes stage s+5.
       const int ahead = S - 2 - s_idx;
-      if (CH_DBG & 64) {
+      if ((CH_DBG & 64) && !FRONT) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         if (lane == 0) *(unsigned long long*)(smem + CH_RING + CH_PAR + (wid * 104 + 2 * s_idx) * 8) = t0;
       }
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(CH_DBG & 32)) asm volatile("s_barrier" ::: "memory");
-      if (CH_DBG & 64) {
+      if ((CH_DBG & 64) && !FRONT) {
         const unsigned long long t1 = __builtin_readcyclecounter();
         if (lane == 0) *(unsigned long long*)(smem + CH_RING + CH_PAR + (wid * 104 + 2 * s_idx + 1) * 8) = t1;
       }
@@ -181,6 +188,9 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       cur = nxt;
       nxt += VG_CH_STAGE;
       if (nxt >= sbase + lane16 + CH_RING) nxt -= CH_RING;
+      // opaque: in the unrolled stretches the compiler otherwise computes the addresses of every stage up front, keeps them
+      // live across the stream, spills them - and reloads one per stage behind a vmcnt(0) that drains the ring
+      asm volatile("" : "+v"(cur), "+v"(nxt));
       ++s_idx;
     };
     // N-major stage [64 n][192 k] (fragment f = 4 ss + jj: consecutive MFMAs go to different accumulators): acc1[jj] += W1 frag x A[6 U + ss]
@@ -189,7 +199,6 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       if (!active) return;  // a wave without rows only carries its share of the weight stream (stage_top)
 #pragma unroll
       for (int f = 0; f < 24; ++f) {
-        constexpr int dummy = 0; (void)dummy;
         const int jj = f & 3, ss = f >> 2, fa = f + CH_LA;
         if (fa < 24) CH_STEP(acc1[jj], F[f % CH_QN], A[6 * U + ss], F[fa % CH_QN], cur, fa * 1024);
         else CH_STEP(acc1[jj], F[f % CH_QN], A[6 * U + ss], F[fa % CH_QN], nxt, (fa - 24) * 1024);
@@ -210,7 +219,14 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
     // (fc2's fragment, k order P) and one register of byte codes; the accumulator is cleared for the next group
     uint32_t codes[4];
     u32x4 bq[2];  // bias quads in flight (requested >= LA steps before their use: the counted waits of the steps in between cover them)
-    unsigned pbt = pb1;
+    // address of b1[64 t + 4 g ..] in the parameter block (+ 64 jj per tile): rebuilt per group from the lane offset that is live anyway -
+    // kept across the stream it was spilled and came back behind a vmcnt(0), twice per group
+    auto bias_addr = [&](int t) {
+      unsigned l16 = lane16;
+      asm volatile("" : "+v"(l16));
+      return sbase + (unsigned)(CH_RING + CH_PAR_B1) + 256u * (unsigned)t + ((l16 >> 4) & 0x30u);
+    };
+    unsigned pbt = bias_addr(0);
     auto bias_req = [&bq, &pbt](auto jj_c) {
       constexpr int JJ = decltype(jj_c)::value;
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[JJ & 1]) : "v"(pbt), "n"(64 * JJ) : "memory");
@@ -241,15 +257,129 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       }
     };
     auto no_hook = [](int) {};
+    // Row epilogue in registers, for the 16 x 384 accumulators of a Linear whose output is the embedding.  Per tile pair p a lane
+    // holds, behind the permlane swap, columns 32 p + cg .. + 7 of its row:  y = res + drop(acc + bias), rounded to bf16 ONCE (what
+    // the unfused kernels stored) and written; with LN: the statistics of the rounded values, yn = LayerNorm(y) written and -
+    // FRAGS - left in `fr` as the next Linear's A fragments (k order S: exactly these 8 columns per lane and k-step).
+    // Everything it addresses with is derived HERE from opaque copies: hoisted above the stream its addresses would stay live
+    // across it and be spilled (first version: 87 registers, reloaded one vmcnt(0) at a time).
+    auto row_epi = [&](auto frags_c, auto batch_c, f32x4 (&acc)[24], u32x4 (&fr)[12], int par_bias, int par_gam, int par_bet, unsigned key_host,
+                       const bf16* resp, bf16* Yp, bf16* Ynp, float* meanp, float* rstdp) {
+      constexpr bool FRAGS = decltype(frags_c)::value;
+      constexpr int RB = decltype(batch_c)::value;  // residual chunks requested ahead (12: all of them, where the registers are free)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      asm volatile("" : "+s"(resp), "+s"(Yp), "+s"(Ynp), "+s"(meanp), "+s"(rstdp));
+      const int eg = ln >> 4;
+      const int ecg = ((eg & 1) << 4) + ((eg & 2) << 2);
+      const int erow = (a.upw * tile + wid) * 16 + (ln & 15);
+      const unsigned char* par = smem + CH_RING;
+      const unsigned dthr = a.drop_thresh, dkey = vg_drop_key(key_host, a.drop_step);
+      const float dscale = a.drop_scale;
+      const unsigned drm = a.drop_row_mul > 1 ? (unsigned)a.drop_row_mul : 1u;
+      u32x4 rv[RB];
+      auto ld_res = [&](int p) {
+        u32x4 r = (u32x4){0u, 0u, 0u, 0u};
+        if (resp) r = *(const u32x4*)(resp + (size_t)erow * VG_CH_E + 32 * p + ecg);
+        return r;
+      };
+#pragma unroll
+      for (int p = 0; p < RB; ++p) rv[p] = ld_res(p);
+      u32x4 yk[12];
+      float sm = 0.f;
+#pragma unroll
+      for (int p = 0; p < 12; ++p) {
+        const int c0 = 32 * p + ecg;
+        const u32x4 rc = rv[p % RB];
+        if (p + RB < 12) rv[p % RB] = ld_res(p + RB);
+        const f32x4 bA = *(const f32x4*)(par + par_bias + 4 * c0), bB = *(const f32x4*)(par + par_bias + 4 * c0 + 16);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][r]), __float_as_uint(acc[2 * p + 1][r]), false, false);
+          v[r] = __uint_as_float(sw[0]) + bA[r];
+          v[r + 4] = __uint_as_float(sw[1]) + bB[r];
+        }
+        if (dthr) {
+          const unsigned i4 = ((unsigned)erow * drm * (unsigned)VG_CH_E + (unsigned)c0) >> 2;
+          const unsigned w0 = vg_drop_word(dkey, i4), w1 = vg_drop_word(dkey, i4 + 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] *= vg_drop_factor(w0, r, dthr, dscale); v[r + 4] *= vg_drop_factor(w1, r, dthr, dscale); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t w = ch_pk(v[2 * q] + ch_lo(rc[q]), v[2 * q + 1] + ch_hi(rc[q]));
+          yk[p][q] = w;
+          sm += ch_lo(w); sm += ch_hi(w);
+        }
+        *(u32x4*)(Yp + (size_t)erow * VG_CH_E + c0) = yk[p];
+        asm volatile("" ::: "memory");  // the scheduler otherwise hoists the bias / residual loads of all 12 pairs to the top: 100+ registers
+      }
+      if (Ynp) {
+        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+        const float mu = sm * (1.0f / VG_CH_E);
+        float q2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 12; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float c0 = ch_lo(yk[p][q]) - mu, c1 = ch_hi(yk[p][q]) - mu;
+            q2 += c0 * c0; q2 += c1 * c1;
+          }
+        q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
+        const float rs = rsqrtf(fmaf(q2, 1.0f / VG_CH_E, a.eps));
+        if (eg == 0) { meanp[erow] = mu; rstdp[erow] = rs; }
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {
+          const int c0 = 32 * p + ecg;
+          const f32x4 gA = *(const f32x4*)(par + par_gam + 4 * c0), gB = *(const f32x4*)(par + par_gam + 4 * c0 + 16);
+          const f32x4 eA = *(const f32x4*)(par + par_bet + 4 * c0), eB = *(const f32x4*)(par + par_bet + 4 * c0 + 16);
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float g0 = q < 2 ? gA[2 * q] : gB[2 * q - 4], g1 = q < 2 ? gA[2 * q + 1] : gB[2 * q - 3];
+            const float e0 = q < 2 ? eA[2 * q] : eB[2 * q - 4], e1 = q < 2 ? eA[2 * q + 1] : eB[2 * q - 3];
+            o[q] = ch_pk(fmaf((ch_lo(yk[p][q]) - mu) * rs, g0, e0), fmaf((ch_hi(yk[p][q]) - mu) * rs, g1, e1));
+          }
+          *(u32x4*)(Ynp + (size_t)erow * VG_CH_E + c0) = o;
+          if (FRAGS) fr[p] = o;
+          asm volatile("" ::: "memory");
+        }
+      }
+    };
 
+    if (FRONT) {
+      // ---- out-projection: 12 K-major stages into the accumulators fc2 uses later; then x_mid, norm2 ----
+#pragma unroll
+      for (int ks = 0; ks < VG_CH_FRONT_STAGES; ++ks) {
+        stage_top(true);  // (no stores in this phase: 9 operations behind the pieces of stage s+1, exactly)
+        if (ks == 0 && active) {
+#pragma unroll
+          for (int q = 0; q < CH_LA; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(F[q]) : "v"(cur), "n"(q * 1024) : "memory");
+        }
+        stage_k(A[ks], no_hook);
+      }
+      // every fragment requested ahead has landed (the compiler does not know the queue's registers are still being written)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+      if (active) {
+        row_epi(std::true_type{}, std::integral_constant<int, 4>{}, acc2, A, CH_PAR_BO, CH_PAR_GAM2, CH_PAR_BET2, a.drop_key_a, a.xin, a.xmid, a.xn_out,
+                a.mean2, a.rstd2);
+#pragma unroll
+        for (int j = 0; j < 24; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // ---- W1(0), its GELU (exposed once) ----
-    stage_top(true);
-    if (active) {
+    // (FRONT: the stores and loads of the epilogue above, ~40 of them, are younger than every piece in flight: 13 is safe from here on)
+    stage_top(!FRONT);
+    if (!FRONT && active) {
 #pragma unroll
       for (int q = 0; q < CH_LA; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(F[q]) : "v"(cur), "n"(q * 1024) : "memory");
     }
     stage_n(std::integral_constant<int, 0>{});
-    stage_top(true);
+    stage_top(!FRONT);
     stage_n(std::integral_constant<int, 1>{});
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results, before the VALU reads them
     if (active) {
@@ -270,7 +400,7 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
       constexpr int HB = decltype(hb_c)::value;
       stage_top(); stage_n(std::integral_constant<int, 0>{});
       stage_top(); stage_n(std::integral_constant<int, 1>{});
-      pbt = pb1 + 256u * (unsigned)(t + 1);
+      pbt = bias_addr(t + 1);
       stage_top();
       stage_k(hid[HB][0], [&](int f) {
         if (f == 0) bias_req(std::integral_constant<int, 0>{});
@@ -297,91 +427,17 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
     stage_top(); stage_k(hid[1][1], no_hook);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // (the look-ahead reads past the last stage are discarded)
 
-    if (CH_DBG & 64) {
+    if ((CH_DBG & 64) && !FRONT) {
       const unsigned long long t2 = __builtin_readcyclecounter();
       if (lane == 0) *(unsigned long long*)(smem + CH_RING + CH_PAR + (wid * 104 + 2 * S) * 8) = t2;
     }
     // ================================================ epilogue ================================================
-    // Per tile pair p a lane holds, after the swap, columns 32 p + cg .. + 7 of its row: Y = res + drop(acc + b2) rounded to
-    // bf16 ONCE (what the unfused pair stored), the LayerNorm statistics are those of the rounded values.
-    if (active && !(CH_DBG & 128)) {
-      // everything the epilogue addresses with is derived HERE from opaque copies: hoisted above the stream its addresses
-      // would stay live across it and be spilled (first version: 87 registers, reloaded one vmcnt(0) at a time)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      VgChainMlpArgs e = a;
-      asm volatile("" : "+s"(e.res), "+s"(e.Y), "+s"(e.Yn), "+s"(e.mean_out), "+s"(e.rstd_out));
-      const int eg = ln >> 4;
-      const int ecg = ((eg & 1) << 4) + ((eg & 2) << 2);
-      const int erow = (e.upw * tile + wid) * 16 + (ln & 15);
-      const unsigned char* par = smem + CH_RING;
-      const unsigned dthr = e.drop_thresh, dkey = vg_drop_key(e.drop_key, e.drop_step);
-      const float dscale = e.drop_scale;
-      const unsigned drm = e.drop_row_mul > 1 ? (unsigned)e.drop_row_mul : 1u;
-      u32x4 rv[12];
-#pragma unroll
-      for (int p = 0; p < 12; ++p) {
-        rv[p] = (u32x4){0u, 0u, 0u, 0u};
-        if (e.res) rv[p] = *(const u32x4*)(e.res + (size_t)erow * VG_CH_E + 32 * p + ecg);
-      }
-      u32x4 yk[12];
-      float sm = 0.f;
-#pragma unroll
-      for (int p = 0; p < 12; ++p) {
-        const int c0 = 32 * p + ecg;
-        const f32x4 bA = *(const f32x4*)(par + CH_PAR_B2 + 4 * c0), bB = *(const f32x4*)(par + CH_PAR_B2 + 4 * c0 + 16);
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc2[2 * p][r]), __float_as_uint(acc2[2 * p + 1][r]), false, false);
-          v[r] = __uint_as_float(sw[0]) + bA[r];
-          v[r + 4] = __uint_as_float(sw[1]) + bB[r];
-        }
-        if (dthr) {
-          const unsigned i4 = ((unsigned)erow * drm * (unsigned)VG_CH_E + (unsigned)c0) >> 2;
-          const unsigned w0 = vg_drop_word(dkey, i4), w1 = vg_drop_word(dkey, i4 + 1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] *= vg_drop_factor(w0, r, dthr, dscale); v[r + 4] *= vg_drop_factor(w1, r, dthr, dscale); }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t w = ch_pk(v[2 * q] + ch_lo(rv[p][q]), v[2 * q + 1] + ch_hi(rv[p][q]));
-          yk[p][q] = w;
-          sm += ch_lo(w); sm += ch_hi(w);
-        }
-        *(u32x4*)(e.Y + (size_t)erow * VG_CH_E + c0) = yk[p];
-      }
-      if (e.Yn) {
-        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
-        const float mu = sm * (1.0f / VG_CH_E);
-        float q2 = 0.f;
-#pragma unroll
-        for (int p = 0; p < 12; ++p)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float c0 = ch_lo(yk[p][q]) - mu, c1 = ch_hi(yk[p][q]) - mu;
-            q2 += c0 * c0; q2 += c1 * c1;
-          }
-        q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
-        const float rs = rsqrtf(fmaf(q2, 1.0f / VG_CH_E, e.eps));
-        if (eg == 0) { e.mean_out[erow] = mu; e.rstd_out[erow] = rs; }
-#pragma unroll
-        for (int p = 0; p < 12; ++p) {
-          const int c0 = 32 * p + ecg;
-          const f32x4 gA = *(const f32x4*)(par + CH_PAR_GAM + 4 * c0), gB = *(const f32x4*)(par + CH_PAR_GAM + 4 * c0 + 16);
-          const f32x4 eA = *(const f32x4*)(par + CH_PAR_BET + 4 * c0), eB = *(const f32x4*)(par + CH_PAR_BET + 4 * c0 + 16);
-          u32x4 o;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float g0 = q < 2 ? gA[2 * q] : gB[2 * q - 4], g1 = q < 2 ? gA[2 * q + 1] : gB[2 * q - 3];
-            const float e0 = q < 2 ? eA[2 * q] : eB[2 * q - 4], e1 = q < 2 ? eA[2 * q + 1] : eB[2 * q - 3];
-            o[q] = ch_pk(fmaf((ch_lo(yk[p][q]) - mu) * rs, g0, e0), fmaf((ch_hi(yk[p][q]) - mu) * rs, g1, e1));
-          }
-          *(u32x4*)(e.Yn + (size_t)erow * VG_CH_E + c0) = o;
-        }
-      }
-    }
-    if (CH_DBG & 64) {
+    // Y = res + drop(fc2 + b2) and the LayerNorm behind it (the next block's norm1); FRONT: the residual is the x_mid this lane
+    // stored behind the out-projection (same addresses, same thread: program order makes it visible)
+    if (active && !(CH_DBG & 128))
+      row_epi(std::false_type{}, std::integral_constant<int, 12>{}, acc2, A, CH_PAR_B2, CH_PAR_GAM, CH_PAR_BET, a.drop_key, FRONT ? (const bf16*)a.xmid : a.res, a.Y,
+              a.Yn, a.mean_out, a.rstd_out);
+    if ((CH_DBG & 64) && !FRONT) {
       const unsigned long long t3 = __builtin_readcyclecounter();
       if (lane == 0) *(unsigned long long*)(smem + CH_RING + CH_PAR + (wid * 104 + 2 * S + 1) * 8) = t3;
       __syncthreads();
@@ -394,28 +450,38 @@ __global__ __launch_bounds__(512) void vg_chain_mlp_fwd_kernel(const VgChainMlpA
 
 // ---- chain image ---------------------------------------------------------------------------------------------------
 // thread = one 16-byte chunk (8 bf16) of the image: stage s, fragment f, lane l
-__global__ __launch_bounds__(256) void vg_chain_mlp_pack_kernel(const bf16* __restrict__ W1, const bf16* __restrict__ W2,
-                                                                bf16* __restrict__ img, int k_in) {
+__global__ __launch_bounds__(256) void vg_chain_pack_kernel(const bf16* __restrict__ Wo, const bf16* __restrict__ W1, const bf16* __restrict__ W2,
+                                                            bf16* __restrict__ img, int k_in, int front) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= VG_CH_MLP_STAGES * 1536) return;
-  const int s = c / 1536, f = (c % 1536) >> 6, l = c & 63, g = l >> 4, li = l & 15;
-  // schedule: stages 0,1 = W1(0); then for t = 0..10: W1(t+1) (2 stages), W2(t) (2 stages); 46,47 = W2(11)
-  bool is_w1; int t, u;
-  if (s < 2) { is_w1 = true; t = 0; u = s; }
-  else if (s >= 46) { is_w1 = false; t = 11; u = s - 46; }
-  else { const int q = (s - 2) >> 2, r = (s - 2) & 3; is_w1 = r < 2; t = is_w1 ? q + 1 : q; u = r & 1; }
+  const int nst = VG_CH_MLP_STAGES + (front ? VG_CH_FRONT_STAGES : 0);
+  if (c >= nst * 1536) return;
+  int s = c / 1536;
+  const int f = (c % 1536) >> 6, l = c & 63, g = l >> 4, li = l & 15;
   const bf16* src; int korder;
-  if (is_w1) {  // [64 n][192 k]: fragment f = 4 ss + jj
-    const int jj = f & 3, ss = f >> 2;
-    src = W1 + (size_t)(64 * t + 16 * jj + li) * VG_CH_E + 192 * u + 32 * ss;
-    korder = k_in;
-  } else {      // [384 n][32 k]: fragment f = n-tile
-    src = W2 + (size_t)(16 * f + li) * VG_CH_HID + 64 * t + 32 * u;
-    korder = VG_CH_KP;
+  if (front && s < VG_CH_FRONT_STAGES) {  // out-projection, [384 n][32 k] per stage, A straight from memory
+    src = Wo + (size_t)(16 * f + li) * VG_CH_E + 32 * s;
+    korder = VG_CH_KNAT;
+  } else {
+    if (front) s -= VG_CH_FRONT_STAGES;
+    // schedule: stages 0,1 = W1(0); then for t = 0..10: W1(t+1) (2 stages), W2(t) (2 stages); 46,47 = W2(11)
+    bool is_w1; int t, u;
+    if (s < 2) { is_w1 = true; t = 0; u = s; }
+    else if (s >= 46) { is_w1 = false; t = 11; u = s - 46; }
+    else { const int q = (s - 2) >> 2, r = (s - 2) & 3; is_w1 = r < 2; t = is_w1 ? q + 1 : q; u = r & 1; }
+    if (is_w1) {  // [64 n][192 k]: fragment f = 4 ss + jj
+      const int jj = f & 3, ss = f >> 2;
+      src = W1 + (size_t)(64 * t + 16 * jj + li) * VG_CH_E + 192 * u + 32 * ss;
+      korder = k_in;
+    } else {      // [384 n][32 k]: fragment f = n-tile
+      src = W2 + (size_t)(16 * f + li) * VG_CH_HID + 64 * t + 32 * u;
+      korder = VG_CH_KP;
+    }
   }
   bf16x8 v;
   if (korder == VG_CH_KNAT) {
     v = *(const bf16x8*)(src + 8 * g);
+  } else if (korder == VG_CH_KS) {
+    v = *(const bf16x8*)(src + ((g & 1) << 4) + ((g & 2) << 2));
   } else {
     const bf16x4 lo = *(const bf16x4*)(src + 4 * g), hi = *(const bf16x4*)(src + 16 + 4 * g);
     v = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -424,8 +490,13 @@ __global__ __launch_bounds__(256) void vg_chain_mlp_pack_kernel(const bf16* __re
 }
 
 int vg_chain_mlp_pack_launch(const bf16* W1, const bf16* W2, bf16* img, int k_in, hipStream_t st) {
-  if (!W1 || !W2 || !img || (k_in != VG_CH_KNAT && k_in != VG_CH_KP)) return -1;
-  hipLaunchKernelGGL(vg_chain_mlp_pack_kernel, dim3(VG_CH_MLP_STAGES * 1536 / 256), dim3(256), 0, st, W1, W2, img, k_in);
+  if (!W1 || !W2 || !img || (k_in != VG_CH_KNAT && k_in != VG_CH_KP && k_in != VG_CH_KS)) return -1;
+  hipLaunchKernelGGL(vg_chain_pack_kernel, dim3(VG_CH_MLP_STAGES * 1536 / 256), dim3(256), 0, st, (const bf16*)nullptr, W1, W2, img, k_in, 0);
+  return (int)hipGetLastError();
+}
+int vg_chain_block_pack_launch(const bf16* Wo, const bf16* W1, const bf16* W2, bf16* img, hipStream_t st) {
+  if (!Wo || !W1 || !W2 || !img) return -1;
+  hipLaunchKernelGGL(vg_chain_pack_kernel, dim3((VG_CH_MLP_STAGES + VG_CH_FRONT_STAGES) * 1536 / 256), dim3(256), 0, st, Wo, W1, W2, img, VG_CH_KS, 1);
   return (int)hipGetLastError();
 }
 
@@ -440,8 +511,10 @@ int vg_chain_mlp_fwd_launch(const VgChainMlpArgs& a0, hipStream_t st) {
   a.stamps = g_ch_stamps;
 #endif
   if (a.M < 16 || (a.M & 15) || (a.ldx & 7)) return 0;
-  if (!a.xn || !a.img || !a.b1 || !a.b2 || !a.a1 || !a.z8 || !a.Y) return -1;
+  const bool front = a.ao != nullptr;
+  if (!(front ? (const void*)a.ao : (const void*)a.xn) || !a.img || !a.b1 || !a.b2 || !a.a1 || !a.z8 || !a.Y) return -1;
   if (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta)) return -1;
+  if (front && (!a.xmid || !a.xn_out || !a.mean2 || !a.rstd2 || !a.gamma2 || !a.beta2)) return -1;
   if ((long long)a.M * (a.drop_row_mul > 1 ? a.drop_row_mul : 1) * VG_CH_E >= (1LL << 32)) return 0;  // dropout index arithmetic is 32-bit
   a.units = a.M / 16;
   // units per workgroup tile = active waves: as few as fill the chip's 256 CUs once (a small problem is one or two waves per
@@ -450,7 +523,8 @@ int vg_chain_mlp_fwd_launch(const VgChainMlpArgs& a0, hipStream_t st) {
   if (a.upw > 8) a.upw = 8;
   const int ntiles = (a.units + a.upw - 1) / a.upw;
   const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL(vg_chain_mlp_fwd_kernel, dim3(grid), dim3(512), 0, st, a);
+  if (front) hipLaunchKernelGGL(vg_chain_fwd_kernel<true>, dim3(grid), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(vg_chain_fwd_kernel<false>, dim3(grid), dim3(512), 0, st, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }
