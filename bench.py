@@ -257,6 +257,9 @@ def main():
                     help="data parallel only, 1: exchange the generator's 12.6 M-parameter mapping gradient as bf16 (halves the one exchange "
                          "that cannot hide behind compute, but the sum is then formed in bf16); default 0: the exact fp32 all-reduce, the "
                          "reference's arithmetic - what a multi-GPU headline must be measured on (VERDICT r3 weak 7)")
+    ap.add_argument("--shard-mapping-update", type=int, default=0,
+                    help="data parallel only, 1: reduce-scatter the mapping gradient in fp32, AdamW on each rank's share, all-gather the updated bf16 "
+                         "shadow (exact sums, 3/4 of the all-reduce's bytes, 1/world of AdamW's traffic on that layer); default 0: all-reduce")
     ap.add_argument("--no-fuse", action="store_true", help="run D(real) and D(fake) as two passes like the reference")
     ap.add_argument("--dropout", type=int, default=1, help="1: reference train-mode dropout (D 0.1 at 13 sites, G 0.2 at 8 sites), 0: none")
     ap.add_argument("--fp8-attention", type=int, default=-1,
@@ -337,7 +340,8 @@ def main():
                                dropout=0.2 if args.dropout else 0.0).to(dev).train()
         eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                         concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
-                        compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, gp_weight=args.gp,
+                        compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, shard_mapping_update=bool(args.shard_mapping_update) and world > 1,
+                        gp_weight=args.gp,
                         dense_top_block=bool(args.dense_top_block))
         return geo, G, eng, fp8
 
@@ -420,7 +424,7 @@ def main():
                        "fp8_attention": fp8_attn,
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "gp_weight": args.gp, "dropout": {"D": eng.p_d, "G": eng.p_g},
                        "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": eng.graph_active,
-                       "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1,
+                       "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1, "shard_mapping_update": eng.shard_map,
                        "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "flops_executed_per_image_step": f_exec,
                        "pruned": None if args.dense_top_block else "top encoder block behind its attention runs on the CLS rows only (the classifier reads "

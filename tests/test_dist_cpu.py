@@ -46,6 +46,25 @@ def _worker(rank, world, port, out):
         untouched = (torch.arange(1000, dtype=torch.float32) * 0.37 + 0.011) * (rank + 1)
         assert torch.equal(flat[200:800], want[200:800].float()), "bf16 exchange"
         assert torch.equal(flat[:200], untouched[:200]) and torch.equal(flat[800:], untouched[800:])
+        # (a'') the sharded update's exchange (GanEngine(shard_mapping_update=True)): after the reduce-scatter this rank's share holds
+        #       the SUM over the ranks; after "updating" only that share, the all-gather gives every rank every share
+        base = torch.arange(1000, dtype=torch.float32) * 0.5 + 1.0
+        flat = base * (rank + 1)
+        a, b = sync.share(200, 800)
+        assert (b - a) * world == 600 and a == 200 + rank * (600 // world)
+        sync.reduce_scatter_range(flat, 200, 800)
+        sync.wait()
+        assert torch.equal(flat[a:b], base[a:b] * tot), "this rank's share must hold the sum"
+        assert torch.equal(flat[:200], base[:200] * (rank + 1)) and torch.equal(flat[800:], base[800:] * (rank + 1))
+        upd = torch.zeros(1000)
+        upd[a:b] = flat[a:b] * 2 + rank          # each rank updates its own share only
+        sync.all_gather_range(upd, 200, 800)
+        sync.wait()
+        for r in range(world):
+            per = 600 // world
+            lo_, hi_ = 200 + r * per, 200 + (r + 1) * per
+            assert torch.equal(upd[lo_:hi_], base[lo_:hi_] * tot * 2 + r), "all-gather of the updated shares"
+        assert float(upd[:200].abs().max()) == 0.0 and float(upd[800:].abs().max()) == 0.0
         # (b) sharded D gradient == global-batch gradient
         d = vo.VitDims(embed=128, heads=4, layers=1, classes=1)
         st = {k: v.clone().requires_grad_(True) for k, v in vo.init_vit_state(d, 7).items()}

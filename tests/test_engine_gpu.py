@@ -295,21 +295,31 @@ def _dp_worker(rank, world, port, out):
         from vit_gan_amd.modules import ViTDiscriminator
         B = 4
 
-        def run(dp_chunks, compress):
+        def run(dp_chunks, compress, shard=False):
             torch.manual_seed(0)  # identical init on every rank (and for every exchange variant)
             D = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, dropout_rate=0.1, batch_size=B,
                                         transformer_blocks_count=4)).cuda().train()
             G = SirenGenerator(embed=128, layers=3, siren_hidden=256).cuda().train()
-            eng = GanEngine(D, G, batch=B, seed=100 + rank, compress_mapping_grad=compress)
+            eng = GanEngine(D, G, batch=B, seed=100 + rank, compress_mapping_grad=compress, shard_mapping_update=shard)
             eng.dp_chunks = dp_chunks
-            assert eng.world == world and eng.sync.overlap
+            assert eng.world == world and eng.sync.overlap and eng.shard_map == shard
             torch.manual_seed(50 + rank)  # different data / noise per rank
             for _ in range(3):
                 real = torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1
                 losses = eng.step(real)
             torch.cuda.synchronize()
+            stale = G._flat.flat.detach().cpu().clone()
+            eng.gather_master()  # (sharded update: every rank's fp32 master of the mapping layer current again; a no-op otherwise)
+            if shard:
+                w0, w1 = eng._map_range()
+                a_, b_ = eng.sync.share(w0, w1)
+                own = torch.zeros(w1 - w0, dtype=torch.bool)
+                own[a_ - w0:b_ - w0] = True
+                fresh = G._flat.flat.detach().cpu()
+                # the shares this rank does not own had NOT been updated (that is the point), its own share had
+                assert torch.equal(stale[w0:w1][own], fresh[w0:w1][own]) and not torch.equal(stale[w0:w1][~own], fresh[w0:w1][~own])
             return (D.vit._flat.flat.detach().cpu(), G._flat.flat.detach().cpu(), D.vit._flat.grad.detach().cpu(), losses.cpu(),
-                    G._flat.grad.detach().cpu())
+                    G._flat.grad.detach().cpu(), G._flat.shadow.detach().cpu())
         # hipGraph replay cannot capture a gloo exchange: the engine must say so and run eager, never silently
         import warnings
         with warnings.catch_warnings(record=True) as caught:
@@ -322,21 +332,26 @@ def _dp_worker(rank, world, port, out):
         assert any("runs EAGER" in str(w_.message) for w_ in caught)
         assert torch.isfinite(eg.step(torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1)).all()
         del eg, Dg, Gg
-        w, gw, gsum, losses, ggrad = run(3, False)         # D and G backward in 3 pieces, exchange overlapped
-        w1, gw1, _, _, ggrad1 = run(1, False)              # one all-reduce per network after its whole backward
-        w2, gw2, _, _, ggrad2 = run(3, True)               # + mapping-layer gradient exchanged as bf16
+        w, gw, gsum, losses, ggrad, gsh = run(3, False)    # D and G backward in 3 pieces, exchange overlapped
+        w1, gw1, _, _, ggrad1, _ = run(1, False)           # one all-reduce per network after its whole backward
+        w2, gw2, _, _, ggrad2, _ = run(3, True)            # + mapping-layer gradient exchanged as bf16
+        w3, gw3, _, _, _, gsh3 = run(3, False, shard=True)  # mapping layer: reduce-scatter, AdamW on this rank's share, all-gather of the shadow
         gather = [None] * world
-        dist.all_gather_object(gather, (w, gw, gsum, losses, gw2))
+        dist.all_gather_object(gather, (w, gw, gsum, losses, gw2, gsh3, gw3))
         if rank == 0:
             ok = all(torch.equal(gather[0][0], g[0]) and torch.equal(gather[0][1], g[1]) and torch.equal(gather[0][2], g[2])
                      and torch.equal(gather[0][4], g[4]) for g in gather[1:])
             fin = all(torch.isfinite(g[3]).all() for g in gather) and torch.isfinite(w).all()
             differ = not torch.equal(gather[0][3], gather[1][3])  # different shards -> different local losses
             staged_equal = torch.equal(w, w1) and torch.equal(gw, gw1) and torch.equal(ggrad, ggrad1)
+            # sharded update: replicas' bf16 shadows bit-identical after 3 steps, the gathered fp32 master bit-identical between the ranks,
+            # and equal to the replicated update's (two ranks: a + b is the same sum in either exchange) - weights of D untouched by it
+            sharded_ok = (all(torch.equal(gather[0][5], g[5]) and torch.equal(gather[0][6], g[6]) for g in gather[1:])
+                          and torch.equal(gw3, gw) and torch.equal(gsh3, gsh) and torch.equal(w3, w))
             # bf16 exchange of the mapping gradient: same update direction for all but noise-level entries
             rel = float((ggrad2 - ggrad).abs().max()) / float(ggrad.abs().max())
             compressed_close = rel < 2.0 ** -7 and float((gw2 - gw).abs().max()) < 3.1e-3 and not torch.equal(ggrad2, ggrad)
-            out.put(("ok", (ok, bool(fin), differ, staged_equal, compressed_close, rel)))
+            out.put(("ok", (ok, bool(fin), differ, staged_equal, compressed_close, rel, sharded_ok)))
     except Exception as e:
         import traceback
         out.put(("err", f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()[-1500:]}"))
@@ -349,7 +364,8 @@ def test_two_rank_data_parallel_engine_on_one_gpu():
     """world_size 2 through the real engine path (staged D and G backward + overlapped ranged all-reduce on a side
     stream + 1/world folded into AdamW): replicas must stay bit-identical, gradients must be the all-reduced sum; the
     staged exchange must equal one all-reduce per network bitwise; the bf16-compressed mapping gradient stays within
-    2^-7 of the fp32 exchange."""
+    2^-7 of the fp32 exchange; the sharded update of the mapping layer (reduce-scatter, AdamW on each rank's share, all-gather of the
+    bf16 shadow) leaves bit-identical replicas and the replicated update's weights."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -364,11 +380,12 @@ def test_two_rank_data_parallel_engine_on_one_gpu():
     for p in procs:
         p.join(timeout=120)
     assert status == "ok", val
-    same, finite, differ, staged_equal, compressed_close, rel = val
+    same, finite, differ, staged_equal, compressed_close, rel, sharded_ok = val
     assert same, "replicas diverged: weights / reduced gradients differ between ranks"
     assert finite and differ
     assert staged_equal, "staged (overlapped) D / G exchange must equal the single all-reduce bit for bit"
     assert compressed_close, f"bf16 exchange of the mapping gradient: relative deviation {rel}"
+    assert sharded_ok, "sharded update of the mapping layer: replicas / the replicated update differ"
 
 
 def test_engine_step_with_patch_grid_generator_at_c4_shape():
@@ -527,13 +544,15 @@ def _rccl_worker(port, out):
         from vit_gan_amd.modules import ViTDiscriminator
         B = 16
         res = []
-        for use_graph in (False, True):
+        # (eager, graph) with the bf16 mapping exchange, then (eager, graph) with the sharded update of the mapping layer: on one rank
+        # the reduce-scatter / all-gather are identities, but they are RCCL's calls, on the side stream, inside the capture
+        for use_graph, shard in ((False, False), (True, False), (False, True), (True, True)):
             torch.manual_seed(0)
             D = ViTDiscriminator(Config(embeddings_dimension=128, classes_count=1, batch_size=B, transformer_blocks_count=3)).cuda().train()
             G = SirenGenerator(embed=128, layers=2, siren_hidden=256).cuda().train()
             eng = GanEngine(D, G, batch=B, seed=4, use_graph=use_graph, external_noise=True, exchange_single_rank=True,
-                            compress_mapping_grad=True)
-            assert eng.sync.active and eng.sync.overlap
+                            compress_mapping_grad=not shard, shard_mapping_update=shard)
+            assert eng.sync.active and eng.sync.overlap and eng.shard_map == shard
             g = torch.Generator().manual_seed(9)
             ls = []
             for _ in range(3):
@@ -544,8 +563,8 @@ def _rccl_worker(port, out):
             res.append((torch.stack(ls).cpu(), D.vit._flat.flat.detach().cpu().clone(), G._flat.flat.detach().cpu().clone(),
                         eng.graph_active, eng.graph_fallback_reason))
             eng.close()
-        graph_ok = res[1][3] and res[1][4] is None
-        same = all(torch.equal(a, b) for a, b in zip(res[0][:3], res[1][:3]))
+        graph_ok = res[1][3] and res[1][4] is None and res[3][3] and res[3][4] is None
+        same = all(torch.equal(a, b) for a, b in zip(res[0][:3], res[1][:3])) and all(torch.equal(a, b) for a, b in zip(res[2][:3], res[3][:3]))
         out.put(("ok", (ok and graph_ok and same, dist.get_backend(), res[1][4])))
         dist.destroy_process_group()
     except Exception as e:

@@ -87,6 +87,67 @@ class GradSync:
             else:
                 self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    # ---- sharded update of one large layer (the generator's 12.6 M-parameter mapping Linear) ---------------------------------------
+    # Its gradient is final only when the step's last kernel has run, so its exchange cannot hide behind compute.  Instead of an
+    # all-reduce (2 (N-1)/N S on the wire) every rank receives the SUM of ONE 1/N share (reduce-scatter: (N-1)/N S, fp32 in the sum),
+    # updates that share alone (AdamW on 1/N of the layer) and the updated bf16 shadow shares are all-gathered ((N-1)/N S/2):
+    # 0.57 -> 0.43 ms at 8 GPUs by the ring model, the sums exact, AdamW's traffic on the layer divided by N.
+    def share(self, lo: int, hi: int):
+        """[begin, end) of this rank's share of flat[lo:hi]; the range must divide by the world size."""
+        n = hi - lo
+        if n % self.world:
+            raise ValueError(f"range of {n} elements does not divide over {self.world} ranks")
+        per = n // self.world
+        return lo + self.rank * per, lo + (self.rank + 1) * per
+
+    def reduce_scatter_range(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """SUM over the ranks of flat[lo:hi]; afterwards this rank's share (``share(lo, hi)``) holds the sum, the rest of the
+        range is unspecified.  RCCL: a reduce-scatter into a scratch share, copied into place on the communication stream; other
+        backends (gloo has no reduce-scatter): an all-reduce of the range - the same sums."""
+        if not self.active or hi <= lo:
+            return
+        a, b = self.share(lo, hi)
+        view = flat[lo:hi]
+        native = dist.get_backend(self.group) == "nccl"
+
+        def run():
+            if native:
+                out = torch.empty(b - a, dtype=flat.dtype, device=flat.device)
+                dist.reduce_scatter_tensor(out, view, op=dist.ReduceOp.SUM, group=self.group)
+                flat[a:b].copy_(out)
+            else:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.overlap:
+            run()
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            run()
+
+    def all_gather_range(self, buf: torch.Tensor, lo: int, hi: int) -> None:
+        """Every rank's share of buf[lo:hi] (as dealt by ``share``) to all ranks, in place."""
+        if not self.active or hi <= lo:
+            return
+        a, b = self.share(lo, hi)
+        view = buf[lo:hi]
+
+        def run():
+            mine = buf[a:b].clone()  # (the collective's input must not alias its output)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(view, mine, group=self.group)
+            else:
+                dist.all_gather(list(view.chunk(self.world)), mine, group=self.group)
+        if not self.overlap:
+            run()
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            run()
+
     def wait(self) -> None:
         """Make the current stream wait for every all-reduce launched since the last wait()."""
         if not self.overlap:

@@ -43,7 +43,7 @@ class GanEngine:
                  concurrent_wgrad: bool = False, clip_d: Optional[float] = None, clip_g: Optional[float] = None,
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
-                 two_stream: bool = False, compress_mapping_grad: bool = False, gp_weight: float = 0.0,
+                 two_stream: bool = False, compress_mapping_grad: bool = False, shard_mapping_update: bool = False, gp_weight: float = 0.0,
                  exchange_single_rank: bool = False, dense_top_block: bool = False):
         """concurrent_wgrad: the discriminator's weight gradients on a side stream beside its input gradients.  Off by default
         since the persistent GEMMs (csrc/gemm_wr.hip, gemm_tn.hip: their workgroups hold the CUs for a whole launch) - the
@@ -69,6 +69,12 @@ class GanEngine:
         the generator's 64 MB, final only when the step's last kernel has run - as bf16 (see GradSync.reduce_range).  The sum is
         then formed in bf16 inside the collective (8 mantissa bits, error growing with the world size), so the default step is
         the exact fp32 all-reduce and a caller that wants the halved link traffic opts in (bench.py does and says so in its line).
+        shard_mapping_update (data parallel only, default OFF): the same layer's gradient is reduce-SCATTERED in fp32 (each rank receives
+        the exact sum of one 1/world share), every rank runs AdamW on its share alone, and the updated bf16 shadow shares - what the
+        GEMMs read - are all-gathered (GradSync.reduce_scatter_range / all_gather_range): exact sums like the default, 3/4 of its bytes
+        on the links, 1/world of AdamW's traffic on the layer.  The fp32 master (and AdamW's moments) of the shares a rank does not
+        own go stale on that rank: ``gather_master()`` brings the master up to date before a ``state_dict()`` is taken.  Not with
+        ``clip_g`` (the clipping norm is taken over the whole gradient) nor together with ``compress_mapping_grad``.
         exchange_single_rank: run the staged backward and its all-reduces on a one-rank group as well (tests: the RCCL
         collectives inside a captured step, on a box with one GPU).
         dense_top_block: compute EVERY row of the top encoder block like the reference's operator graph does.  Default off: behind
@@ -100,6 +106,9 @@ class GanEngine:
         self.clip_d, self.clip_g = clip_d, clip_g
         self.dp_chunks = 3  # pieces of the D / G backward whose gradient exchange overlaps the remaining backward
         self.compress_map = bool(compress_mapping_grad)
+        self._want_shard_map = bool(shard_mapping_update)
+        if self._want_shard_map and (self.compress_map or clip_g is not None):
+            raise ValueError("shard_mapping_update excludes compress_mapping_grad and clip_g")
         self.dense_top = int(bool(dense_top_block))
         self.gp_w = float(gp_weight)
         self.gp_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
@@ -119,6 +128,9 @@ class GanEngine:
         self.pg = process_group
         self.sync = GradSync(process_group, self.dev, overlap=True, single_rank=exchange_single_rank)
         self.world = self.sync.world
+        g_ = generator._dims
+        # (a layer that does not divide over the ranks keeps the all-reduce; a one-rank group - `exchange_single_rank` - runs the same calls)
+        self.shard_map = self._want_shard_map and self.sync.active and (g_.T * g_.E * g_.Z) % (4 * self.world) == 0
         # latent noise drawn on the device (vg_step_inputs): one stream per (seed, rank)
         self._noise_seed = (self.seed * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (self.sync.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         d, g = vit._dims, generator._dims
@@ -248,13 +260,49 @@ class GanEngine:
         d = self.gen._dims
         for s0, s1, lo, hi in backward_pieces(d.L, self.dp_chunks, lay.layer0, lay.layer_stride, fg.total):
             _lib.check(L.vg_gen_backward_stages(C.byref(ng), self.B, _p(self.ws_g), _p(self.dfake), s0, s1, st), "vg_gen_backward_stages")
-            if lo == 0 and self.compress_map:  # [embedding | mapping weight | mapping bias, lowest blocks]
+            if lo == 0 and (self.compress_map or self.shard_map):  # [embedding | mapping weight | mapping bias, lowest blocks]
                 w0, w1 = lay.map_w, lay.map_w + d.T * d.E * d.Z
                 self.sync.reduce_range(fg.grad, 0, w0)
-                self.sync.reduce_range(fg.grad, w0, w1, compress=True)
+                if self.shard_map:
+                    self.sync.reduce_scatter_range(fg.grad, w0, w1)   # this rank keeps the sum of its share only
+                else:
+                    self.sync.reduce_range(fg.grad, w0, w1, compress=True)
                 self.sync.reduce_range(fg.grad, w1, hi)
             else:
                 self.sync.reduce_range(fg.grad, lo, hi)
+
+    def _map_range(self):
+        lay, d = flat.gen_layout(self.gen._dims), self.gen._dims
+        return lay.map_w, lay.map_w + d.T * d.E * d.Z
+
+    def _adamw_g_sharded(self, st) -> None:
+        """The generator's AdamW with the mapping Linear sharded: the whole buffer but that layer as usual, of the layer this rank's
+        share only; then the updated bf16 shadow shares to every rank (the GEMMs of every rank read the whole shadow)."""
+        fg, h, L = self.gen._flat, self.hyp, _lib.lib()
+        w0, w1 = self._map_range()
+        a, b = self.sync.share(w0, w1)
+
+        def upd(lo, hi):
+            if hi <= lo:
+                return
+            off = lambda t, es: C.c_void_p(t.data_ptr() + es * lo)  # noqa: E731
+            _lib.check(L.vg_adamw_step(off(fg.flat, 4), off(fg.grad, 4), off(self.m_g, 4), off(self.v_g, 4), off(fg.shadow, 2), hi - lo,
+                                       self.hyp["lr_g"], h["b1"], h["b2"], h["eps"], h["wd"], 0, _p(self.step_t), 1.0 / self.world, st), "vg_adamw_step")
+        upd(0, w0)
+        upd(a, b)
+        upd(w1, fg.total)
+        self.sync.all_gather_range(fg.shadow, w0, w1)
+        self.sync.wait()
+
+    def gather_master(self) -> None:
+        """shard_mapping_update: bring the fp32 master of the mapping Linear up to date on every rank (each rank updates its share
+        only); call it before ``state_dict()`` / a checkpoint.  A no-op otherwise."""
+        if not self.shard_map:
+            return
+        w0, w1 = self._map_range()
+        self.sync.all_gather_range(self.gen._flat.flat, w0, w1)
+        self.sync.wait()
+        torch.cuda.current_stream().synchronize()
 
     def _adamw(self, fp, m, v, lr, st, clip=None, slot=0):
         h = self.hyp
@@ -413,7 +461,10 @@ class GanEngine:
                        "vg_diversity_loss")
         self._g_backward(ng, st)
         self.sync.wait()
-        self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st, self.clip_g, 1)
+        if self.shard_map:
+            self._adamw_g_sharded(st)
+        else:
+            self._adamw(fg, self.m_g, self.v_g, self.hyp["lr_g"], st, self.clip_g, 1)
 
     # ------------------------------------------------------------------------------------------
     def _state_tensors(self):

@@ -271,6 +271,7 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
             if fid_score < best_fid:
                 best_fid = fid_score
                 if save_artifacts:
+                    eng.gather_master()  # (a sharded update keeps each rank's fp32 master current on its share only)
                     torch.save(gan.state_dict(), os.path.join(dirs.checkpoints, f"best_model_epoch_{epoch}_fid_{int(fid_score)}.pth"))
             log(f"Epoch [{epoch}/{epochs}] | Disc Loss: {d_real + d_fake:.8f}, Gen Loss: {g:.4f} | FID: {fid_score:.4f}")
             if save_artifacts:
@@ -286,6 +287,7 @@ def train_model(config: Optional[Dict[str, Any]] = None, steps_per_epoch: int = 
         model_path = os.path.join(dirs.save, "final_model.ckpt")
         if save_artifacts and fatal is None:  # no further GPU work, no checkpoint of a broken run
             save_figures(dirs.save, disc_losses=disc_losses, gen_losses=gen_losses, fid_scores=fid_scores)
+            eng.gather_master()
             torch.save(gan.state_dict(), model_path)
             save_samples(epoch, construct_noise())
         took = datetime.datetime.now() - dirs.start
