@@ -482,7 +482,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
                 d = dwm * g_s;
               }
               xh[i][j] = h;
-              if (sums) { ag[i][j] = fmaf(d, h, ag[i][j]); ab[i][j] += d; }
+              ag[i][j] = fmaf(d, h, ag[i][j]);  // (unconditional: behind a run-time `sums` each became a v_cndmask - three selects per element)
+              ab[i][j] += d;
               const float gv = d * gm[j];
               gg[i][j] = gv;
               c1 += gv;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
               if (!RW_DBG(8)) *(chunk_t*)(e.dxm + row * RW_E + c) = o;
             }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) if (sums) ac[i][j] += vg_bf2f(o[j]);
+            for (int j = 0; j < CH; ++j) ac[i][j] += vg_bf2f(o[j]);
           }
         }
       }
