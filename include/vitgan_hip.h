@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 8
+#define VG_ABI_VERSION 9
 int vg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -373,6 +373,18 @@ int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, 
 int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img,
                            int want_wgrad, int stage_begin, int stage_end, void* stream);
 
+/* ABI v9.  The WGAN-GP gradient penalty of the reference's Wasserstein step as ONE call (replaces the autograd double backward over
+ * the operator set; reference: gradient_penalty, src/v2/utils.py:124-144, and its call site src/v2/training.py:101-106):
+ *   penalty = mean_b (|| d sum(D(x^_b)) / d x^_b ||_2 - 1)^2,  x^ = eps real + (1 - eps) fake;   net->G += weight * d penalty / d theta;
+ *   *penalty_out = penalty (device float).  real / fake: bf16 [B, C, IH, IH]; eps: device fp32 [B] (the reference draws torch.rand).
+ * ws: a vg_vit_ws_bytes(d, B) workspace (the call runs its own forward in it); ws_pen: vg_vit_penalty_ws_bytes(d, B) bytes.
+ * The discriminator runs in train mode like the reference's does: net->dropout_p / dropout_seed / dropout_step give the masks (one set
+ * for all passes of the call).  net->dense_top and net->ctx are ignored (every row of the top block; one stream).  -3: shapes the
+ * full-row kernels do not take (E other than 384 / 512, B * tokens not a multiple of 16) or attn_fp8 - callers fall back to the
+ * operator set there. */
+long long vg_vit_penalty_ws_bytes(const VgVitDims* d, int B);
+int vg_vit_penalty(const VgVitNet* net, int B, const void* real, const void* fake, const float* eps, float weight, void* ws, void* ws_pen,
+                   float* penalty_out, void* stream);
 /* v1 generator: mapping Linear -> L x TransformerSLN -> SLN -> SIREN x2 (src/v1/generator.py:58-69). */
 typedef struct VgGenDims {
   int Z, T, E, H, L, O, CW; /* latent, tokens, embed, heads, layers, siren hidden, output features per token */

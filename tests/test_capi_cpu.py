@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vitgan_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert set(_lib._SIGNATURES) <= set(names), set(_lib._SIGNATURES) - set(names)
-    assert lib.vg_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.vg_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_argument_validation_without_gpu():

@@ -141,16 +141,18 @@ def test_gradient_penalty_matches_the_reference_fixture():
         u.assert_close(got[k], torch.from_numpy(npz[f"full/{k}"]), 2.0 ** -4, f"{k} vs the reference fixture", floor=1e-5)
 
 
-def test_engine_step_with_gradient_penalty():
+@pytest.mark.parametrize("B", [8, 16])
+def test_engine_step_with_gradient_penalty(B):
     """The reference's Wasserstein discriminator step with the penalty (training.py:83-106: critic loss + lambda_gp * gp,
-    clipping) through GanEngine vs the step oracle, same noise and the same epsilon."""
+    clipping) through GanEngine vs the step oracle, same noise and the same epsilon.  B = 16: the penalty as one C call
+    (vg_vit_penalty; 16 x 65 rows are whole units of 16); B = 8: the operator set through autograd."""
     from vit_gan_amd.engine import GanEngine
     from test_engine_gpu import _build
-    B = 8
     D, G, oracle = _build(B, "wasserstein")
     oracle.gp_weight = 10.0
     oracle.clip_d = 5.0
     eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True)
+    assert eng.gp_c_call == (B == 16)
     g = torch.Generator().manual_seed(0)
     real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
     z = torch.randn(B, 1024, generator=g)
@@ -173,12 +175,13 @@ def test_engine_step_with_gradient_penalty():
         GanEngine(D, G, batch=B, gp_weight=1.0, two_stream=True)
 
 
-def test_engine_step_with_gradient_penalty_replays_as_a_graph():
-    """The penalty's autograd passes captured in the step's hipGraph: three replayed steps equal three eager steps bit for bit
-    (dropout off and epsilon fixed: the only randomness of the penalty pass), and the capture really is active."""
+@pytest.mark.parametrize("B,p_drop", [(8, 0.0), (16, 0.0), (16, 0.1)])
+def test_engine_step_with_gradient_penalty_replays_as_a_graph(B, p_drop):
+    """The penalty's passes captured in the step's hipGraph: three replayed steps equal three eager steps bit for bit, and the capture
+    really is active.  B = 8: the autograd passes of the operator set (dropout off and epsilon fixed: the only randomness of that pass
+    is torch's); B = 16: the C call, also with dropout - its masks are the engine's counter-based ones, a function of the step counter."""
     from vit_gan_amd.engine import GanEngine
     from test_engine_gpu import _build
-    B = 8
     g = torch.Generator().manual_seed(0)
     reals = [(torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda() for _ in range(3)]
     zs = [torch.randn(B, 1024, generator=g).cuda() for _ in range(3)]
@@ -187,7 +190,8 @@ def test_engine_step_with_gradient_penalty_replays_as_a_graph():
     for use_graph in (False, True):
         D, G, _ = _build(B, "wasserstein")
         eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True, use_graph=use_graph,
-                        d_dropout=0.0, g_dropout=0.0)
+                        d_dropout=p_drop, g_dropout=p_drop)
+        assert eng.gp_c_call == (B == 16)
         eng.gp_epsilon = eps
         ls = [eng.step(r, z).clone() for r, z in zip(reals, zs)]
         torch.cuda.synchronize()
@@ -236,3 +240,104 @@ def test_deferred_grouped_weight_gradients_equal_autograd(B):
             assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, name   # regrouped fp32 sums of the same bf16 products
         else:
             assert torch.equal(ga, gb), name                                    # everything else took the same path
+
+
+def _penalty_c_call(D, real, fake, eps, weight, p_drop=0.0, seed=11, step=None):
+    """vg_vit_penalty straight through the C ABI: (penalty, flat gradient) of ``weight * penalty`` accumulated into a zeroed buffer."""
+    import ctypes as C
+    from vit_gan_amd import _lib
+    L = _lib.lib()
+    vit = D.vit
+    fl = vit._flat
+    fl.refresh_shadow()
+    fl.grad.zero_()
+    B = real.shape[0]
+    d = vit._dims
+    ws = torch.empty(L.vg_vit_ws_bytes(C.byref(d), B), dtype=torch.uint8, device="cuda")
+    wp = torch.empty(L.vg_vit_penalty_ws_bytes(C.byref(d), B), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(1, dtype=torch.float32, device="cuda")
+    net = _lib.VgVitNet(d, fl.flat.data_ptr(), fl.shadow.data_ptr(), fl.grad.data_ptr(), p_drop, seed, None if step is None else step.data_ptr(), None, 0, 0)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rb, fb = real.to(torch.bfloat16).contiguous(), fake.to(torch.bfloat16).contiguous()
+    e = eps.reshape(-1).float().contiguous()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.vg_vit_penalty(C.byref(net), B, p(rb), p(fb), p(e), float(weight), p(ws), p(wp), p(out), st), "vg_vit_penalty")
+    torch.cuda.synchronize()
+    return float(out), fl.grad.detach().clone()
+
+
+@pytest.mark.parametrize("B,layers", [(16, 2), (32, 3)])
+def test_penalty_c_call_matches_the_operator_set(B, layers):
+    """vg_vit_penalty (forward, input-gradient backward, its double backward and the second backward as ONE C call) against the
+    operator-set form through torch autograd (penalty.gradient_penalty, itself pinned to the reference's fixture above): dropout off,
+    the same epsilon.  Both are bf16 pipelines with different fusion (the C call's second backward runs the fused full-row kernels):
+    per tensor within 2^-6 of max|.|, the penalty within 2^-7."""
+    from vit_gan_amd import ops2
+    from vit_gan_amd.penalty import gradient_penalty
+    from test_engine_gpu import _build
+    D, _, _ = _build(B, "wasserstein", layers=layers)
+    D.train()
+    fl = D.vit._flat
+    g = torch.Generator().manual_seed(B)
+    real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
+    fake = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
+    eps = torch.rand(B, 1, 1, 1, generator=g).cuda()
+    w = 10.0
+    fl.attach_grads()
+    fl.grad.zero_()
+    pen = gradient_penalty(D, real, fake, epsilon=eps)
+    with ops2.deferred_weight_grads(fl.grad):
+        (w * pen).backward()
+    torch.cuda.synchronize()
+    ref_pen, ref = float(pen.detach()), fl.grad.detach().clone()
+    got_pen, got = _penalty_c_call(D, real, fake, eps, w)
+    print(f"penalty: C call {got_pen:.6f}  operator set {ref_pen:.6f}")
+    assert abs(got_pen - ref_pen) <= 2.0 ** -7 * abs(ref_pen) + 1e-5
+    # (tensors whose gradient is round-off of an exact zero - the key bias, which the softmax cancels - are held to the buffer's scale)
+    floor = 2.0 ** -10 * float(ref.abs().max())
+    worst, bad = [], []
+    for name, (off, shape) in fl.slots.items():
+        n = int(torch.tensor(shape).prod())
+        a, b = got[off:off + n], ref[off:off + n]
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        worst.append((err / max(scale, floor), name, err, scale))
+        if not err <= 2.0 ** -6 * scale + floor:
+            bad.append((name, err, scale))
+    print("largest deviations:", [(k, f"{v:.2e}", f"{e:.2e}/{sc:.2e}") for v, k, e, sc in sorted(worst, reverse=True)[:8]])
+    assert not bad, bad
+
+
+def test_penalty_c_call_with_dropout_is_the_gradient_of_its_own_value():
+    """Train-mode dropout (the reference's discriminator is in train mode inside gradient_penalty): the five passes of the call must draw
+    the same masks.  A mask mismatch between any two passes leaves the value fine and the gradient wrong, so: the directional derivative
+    of the call's penalty VALUE along its own gradient, by central differences on the fp32 master weights (same seed and step counter =
+    same masks), against |gradient|^2."""
+    from test_engine_gpu import _build
+    B = 16
+    D, _, _ = _build(B, "wasserstein", layers=2)
+    D.train()
+    fl = D.vit._flat
+    g = torch.Generator().manual_seed(5)
+    real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+    fake = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda()
+    eps = torch.rand(B, 1, 1, 1, generator=g).cuda()
+    step = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    pen0, grad = _penalty_c_call(D, real, fake, eps, 1.0, p_drop=0.1, step=step)
+    pen0_off, _ = _penalty_c_call(D, real, fake, eps, 1.0, p_drop=0.0)
+    assert pen0 != pen0_off  # the masks are really on
+    w0 = fl.flat.detach().clone()
+    gn2 = float((grad.double() ** 2).sum())
+    assert gn2 > 0
+    # a step that moves the penalty by a few percent: far above the bf16 noise of its evaluation, still in the linear range
+    h = 0.04 * pen0 / gn2
+    vals = []
+    for sgn in (+1.0, -1.0):
+        with torch.no_grad():
+            fl.flat.copy_(w0 + sgn * h * grad)
+        vals.append(_penalty_c_call(D, real, fake, eps, 1.0, p_drop=0.1, step=step)[0])
+    with torch.no_grad():
+        fl.flat.copy_(w0)
+    fl.refresh_shadow()
+    fd = (vals[0] - vals[1]) / (2 * h)
+    print(f"penalty {pen0:.5f}; directional derivative: finite differences {fd:.5e}  |grad|^2 {gn2:.5e}  ratio {fd / gn2:.3f}")
+    assert 0.8 < fd / gn2 < 1.25

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VITGAN_HIP_LIB", os.path.join(_HERE, "libvitgan_hip.s
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
-ABI_VERSION = 8  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
+ABI_VERSION = 9  # VG_ABI_VERSION of include/vitgan_hip.h this binding was written against
 
 
 class VgVitDims(C.Structure):
@@ -132,6 +132,8 @@ _SIGNATURES = {
     "vg_vit_forward": (c_int, [C.POINTER(VgVitNet), c_int, P, c_int, P, P, P]),
     "vg_vit_backward": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, P]),
     "vg_vit_backward_stages": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_int, c_int, c_int, P]),
+    "vg_vit_penalty_ws_bytes": (c_ll, [C.POINTER(VgVitDims), c_int]),
+    "vg_vit_penalty": (c_int, [C.POINTER(VgVitNet), c_int, P, P, P, c_float, P, P, P, P]),
     "vg_gen_layout": (c_int, [C.POINTER(VgGenDims), C.POINTER(VgGenLayout)]),
     "vg_gen_ws_bytes": (c_ll, [C.POINTER(VgGenDims), c_int]),
     "vg_gen_forward": (c_int, [C.POINTER(VgGenNet), c_int, P, P, P, P]),

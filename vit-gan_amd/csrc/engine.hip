@@ -309,9 +309,11 @@ extern "C" int vg_vit_ws_map(const VgVitDims* d, int B, VgVitWsMap* o) {
   return 0;
 }
 
-extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws, float* logits,
-                              void* stream) {
+// preact (nullable): [L][M][rE] - the gradient penalty's forward keeps fc1's pre-activation (its double backward needs gelu''), not the
+// one-byte gelu' code; only with dense_top (the penalty runs every row of the top block)
+static int vit_forward_impl(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws, float* logits, void* stream, bf16* preact) {
   if (!net || !img || !ws || !logits || B < 1) return -1;
+  if (preact && !net->dense_top) return -3;
   const VgVitDims& d = net->d;
   VgVitLayout lay;
   VG_TRY(vg_vit_layout(&d, &lay));
@@ -414,7 +416,8 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
                               w.rstd2 + (size_t)l * M, M, E, 1e-5f, st));
     }
     // z1 keeps gelu'(pre-activation), the only thing the backward needs of it, as one byte per element
-    VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, (bf16*)z1, nullptr, st, nullptr, 0, 2));
+    if (preact) VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, preact + (size_t)l * M * rE, nullptr, st));
+    else VG_TRY(lin_fwd(xn2, E, Pb + lo + lay.w1, P + lo + lay.b1, a1, M, rE, VG_ACT_GELU, 0.f, nullptr, (bf16*)z1, nullptr, st, nullptr, 0, 2));
     if (rown) {  // X[l+1] = x_mid + drop(fc2(a1)) and the NEXT block's norm1 of it (the last block's output only feeds the CLS rows)
       const bool nx = l + 1 < d.L;
       const long long ln = lo + lay.layer_stride;
@@ -435,13 +438,28 @@ extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int i
   VG_TRY(vg_head_fc2_launch(w.th, P + lay.hw2, P + lay.hb2, logits, B, E, d.Kc, st));
   return 0;
 }
+extern "C" int vg_vit_forward(const VgVitNet* net, int B, const void* img, int img_is_bf16, void* ws, float* logits,
+                              void* stream) {
+  return vit_forward_impl(net, B, img, img_is_bf16, ws, logits, stream, nullptr);
+}
 
 // Backward stages: 0 = classifier head + final LN, 1..L = encoder blocks L-1 .. 0, L+1 = patch embedding.
 // Running [stage_begin, stage_end) lets the caller all-reduce the gradients of finished blocks (a contiguous
 // range of the flat buffer) on another stream while the remaining stages still compute.
-extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
-                                      int stage_begin, int stage_end, void* stream) {
+// The gradient penalty's SECOND backward (vg_vit_penalty below) is this backward with gradients injected at the activations the
+// double backward reaches: dL/d(fc1 pre-activation), dL/d(qkv), dL/d(x_mid), dL/d(X[l]) per block, dL/dX[L] on the CLS rows, and
+// dL/d(classifier fc1 pre-activation) in place of the logits' gradient.
+struct VitInject {
+  const bf16* preact;   // [L][M][rE]: the forward kept fc1's pre-activation (vit_forward_impl) - gelu' is computed from it
+  int head_given;       // w.dzh already holds dL/d(classifier fc1 pre-activation): no logits' backward, no fc2 gradients
+  const bf16* s_xcls;   // [B, E]
+  const bf16 *s_h, *s_xmid, *s_qkv, *s_x;  // block l at + l M {rE, E, 3E, E}
+  bf16* tmp;            // [M, E]: gres + s where the residual-stream gradient is an operand of other launches too
+};
+static int vit_backward_impl(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
+                             int stage_begin, int stage_end, void* stream, const VitInject* inj) {
   if (!net || !ws || !dlogits || B < 1) return -1;
+  if (inj && !net->dense_top) return -3;
   if (stage_begin < 0 || stage_end > net->d.L + 2 || stage_begin >= stage_end) return -2;
   if (want_wgrad && !net->G) return -1;
   const VgVitDims& d = net->d;
@@ -478,7 +496,8 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   if (stage_begin == 0) {
   // ---- classifier head + final LN (CLS rows only) ----
   // dz, and the gradients of fc2 and of fc1's bias as partial rows for the fold at the end of this call: one launch
-  const int head1 = vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr, want_wgrad ? G + lay.hb2 : nullptr,
+  const int head1 = (inj && inj->head_given) ? 0 :
+                    vg_head_bwd_launch(dlogits, P + lay.hw2, w.th, w.dzh, want_wgrad ? G + lay.hw2 : nullptr, want_wgrad ? G + lay.hb2 : nullptr,
                                        B, E, d.Kc, want_wgrad, st, (want_wgrad && d.Kc <= 16) ? w.hpart : nullptr);
   if (head1 < 0) return -head1;
   if (want_wgrad) {
@@ -497,6 +516,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
                             site_key(dr, 2 + 2 * top), dr.scale, dr.step, st, 1, S));
   } else {
     VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)d.L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
+    if (inj && inj->s_xcls) VG_TRY(vg_add_bf16_launch(w.dxcls, inj->s_xcls, w.dxcls, (long long)B * E, st));
     // dL/dX[L]: the CLS rows, zero elsewhere - and its masked copy for the last block's MLP dropout, in the same launch
     VG_TRY(vg_scatter_cls_launch(w.dxcls, w.set[top & 1].gin, B, S, E, st, drop ? w.set[top & 1].gm2 : nullptr, dr.thr, site_key(dr, 2 + 2 * top), dr.scale, dr.step));
   }
@@ -642,13 +662,17 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       else VG_TRY(vg_scatter_cls2_launch(w.t_dao, w.dao, w.t_dxmid, cur.gmid, B, S, E, st));
     } else {
     // d a1 = gb2 W2 ; dz1 = d a1 * gelu'(pre-activation), stored by the forward   (fused epilogue)
-    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
+    if (inj && inj->preact) VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_GELU_GRAD, inj->preact + (size_t)l * M * rE, nullptr, 0.f, st));
+    else VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
+    if (inj && inj->s_h) VG_TRY(vg_add_bf16_launch(cur.dz1, inj->s_h + (size_t)l * M * rE, cur.dz1, (long long)M * rE, st));
+    const bf16* gres2 = g;  // the residual-stream gradient the norm2 backward adds
+    if (inj && inj->s_xmid) { VG_TRY(vg_add_bf16_launch(g, inj->s_xmid + (size_t)l * ME, inj->tmp, (long long)ME, st)); gres2 = inj->tmp; }
     if (rown) {  // fc1 input gradient + norm2 backward + the residual-stream gradient
-      VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid,
+      VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gres2, cur.gmid,
                      drop ? cur.gm1 : nullptr, part2, 1 + 2 * l));
     } else {
       VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-      VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, g, cur.gmid, part2, M, E,
+      VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gres2, cur.gmid, part2, M, E,
                               drop ? cur.gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
     }
     const bf16* gb1 = drop ? cur.gm1 : cur.gmid;  // gradient w.r.t. the out-projection output (before dropout1)
@@ -658,6 +682,7 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
       VG_TRY(vg_attn_cls_bwd_launch(qkv, w.t_ao, w.t_dao, w.t_lse, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), st));
     else
       VG_TRY(vg_attn_bwd_launch(qkv, ao, w.dao, w.lse + (size_t)l * B * d.H * S, cur.dqkv, B, d.H, S, HE, 1.0f / sqrtf((float)HE), net->attn_fp8 ? 2 : 0, st));
+    if (inj && inj->s_qkv) VG_TRY(vg_add_bf16_launch(cur.dqkv, inj->s_qkv + (size_t)l * ME * 3, cur.dqkv, (long long)ME * 3, st));
     if (!rown) VG_TRY(lin_dgrad(cur.dqkv, Pb + lo + lay.wqkv, w.dxn, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     if (pairing) {  // second block of a pair (or the odd one out at the end of this call): its and its partner's weight gradients
       const int idx = l_hi - l;
@@ -668,11 +693,13 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
     // weight-gradient side of block l+1 may still be reading: wait for it first
     if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
       VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[l + 1], 0));
+    const bf16* gres1 = cur.gmid;
+    if (inj && inj->s_x) { VG_TRY(vg_add_bf16_launch(cur.gmid, inj->s_x + (size_t)l * ME, inj->tmp, (long long)ME, st)); gres1 = inj->tmp; }
     if (rown) {  // QKV input gradient + norm1 backward + the residual-stream gradient
-      VG_TRY(row_bwd(cur.dqkv, 3 * E, wp + po_wqkvT, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin,
+      VG_TRY(row_bwd(cur.dqkv, 3 * E, wp + po_wqkvT, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gres1, nxt.gin,
                      drop ? nxt.gm2 : nullptr, part1, l > 0 ? 2 + 2 * (l - 1) : 0));
     } else {
-      VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, cur.gmid, nxt.gin, part1, M, E,
+      VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gres1, nxt.gin, part1, M, E,
                               drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
     }
     if (!want_wgrad) continue;
@@ -724,10 +751,208 @@ extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, cons
   return 0;
 }
 
+extern "C" int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
+                                      int stage_begin, int stage_end, void* stream) {
+  return vit_backward_impl(net, B, ws, dlogits, d_img, want_wgrad, stage_begin, stage_end, stream, nullptr);
+}
 extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float* dlogits, void* d_img, int want_wgrad,
                                void* stream) {
   if (!net) return -1;
   return vg_vit_backward_stages(net, B, ws, dlogits, d_img, want_wgrad, 0, net->d.L + 2, stream);
+}
+
+// =============================================================================================
+//            gradient penalty (src/v2/utils.py:124-144, training.py:101-106) as ONE call
+// =============================================================================================
+// G += weight * d/d theta mean_b (|| d sum(D(x^)) / d x^ ||_2 - 1)^2 at x^ = eps real + (1 - eps) fake: five passes on one stream.
+//   1. forward of x^ (every row of the top block; fc1's pre-activation kept - gelu'' needs it);
+//   2. first backward, input gradient only, UNFUSED and with every intermediate gradient kept per block: they are the "dY operands"
+//      of the second-order operators;
+//   3. n_b = ||g_b||, the penalty, and u = d(weight * penalty) / d g;
+//   4. the backward of pass 2 (the direction u travels UP the network: it is the forward-mode tangent of pass 1): per block the
+//      LayerNorm / attention / GELU second-order kernels (second_order.hip, attention.hip), the Linear layers as forward GEMMs
+//      (d(dY) = ddX W^T) and weight gradients dW += dY^T ddX (one grouped launch per block); each second-order kernel also yields a
+//      gradient with respect to a forward activation (X[l], qkv, x_mid, the fc1 pre-activation) that
+//   5. the ordinary fused backward of pass 1 picks up where it reaches that activation (VitInject) - with nothing arriving from the logits.
+// The operator arithmetic is that of vit-gan_amd/ops2.py (the autograd form this replaces, kept as the reference the tests compare
+// with); dropout draws the engine's counter-based masks of net->dropout_seed, the same in all five passes.
+struct PenWs {
+  float *xhat, *ones, *logits, *pen_img, *pbb;
+  bf16 *h, *gin, *gm2, *da1, *dz1, *dxn2, *gmid, *gm1, *dao, *dqkv, *dxn1, *g0, *g0m, *xcls;
+  bf16 *u_dA, *u_x[2], *u_dxn, *u_dxn2, *u_dqkv, *u_dao, *u_gmid, *u_dz1, *u_da1, *ucls, *u_gc, *u_gpre, *u_gt;
+  bf16 *s_x, *s_qkv, *s_xmid, *s_h, *s_xcls, *tmp;
+};
+static long long carve_pen(const VgVitDims& d, int B, void* base, PenWs& q) {
+  const long long E = d.E, NP = (long long)(d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = (long long)B * S;
+  const long long Kp = (long long)d.C * d.P * d.P, L = d.L, rE = (long long)d.R * E;
+  Carver c{(unsigned char*)base, 0};
+  q.xhat = c.take<float>((long long)B * d.C * d.IH * d.IH);
+  q.ones = c.take<float>((long long)B * d.Kc); q.logits = c.take<float>((long long)B * d.Kc); q.pen_img = c.take<float>(B);
+  q.pbb = c.take<float>((2 * L + 1) * (long long)vg_ln_bwd_bwd_nparts((int)M) * E);
+  q.h = c.take<bf16>(L * M * rE);
+  q.gin = c.take<bf16>(L * M * E); q.gm2 = c.take<bf16>(L * M * E);
+  q.da1 = c.take<bf16>(L * M * rE); q.dz1 = c.take<bf16>(L * M * rE);
+  q.dxn2 = c.take<bf16>(L * M * E); q.gmid = c.take<bf16>(L * M * E); q.gm1 = c.take<bf16>(L * M * E);
+  q.dao = c.take<bf16>(L * M * E); q.dqkv = c.take<bf16>(L * M * 3 * E); q.dxn1 = c.take<bf16>(L * M * E);
+  q.g0 = c.take<bf16>(M * E); q.g0m = c.take<bf16>(M * E); q.xcls = c.take<bf16>(B * E);
+  q.u_dA = c.take<bf16>(B * NP * Kp);
+  q.u_x[0] = c.take<bf16>(M * E); q.u_x[1] = c.take<bf16>(M * E);
+  q.u_dxn = c.take<bf16>(M * E); q.u_dxn2 = c.take<bf16>(M * E); q.u_dqkv = c.take<bf16>(M * 3 * E); q.u_dao = c.take<bf16>(M * E); q.u_gmid = c.take<bf16>(M * E);
+  q.u_dz1 = c.take<bf16>(M * rE); q.u_da1 = c.take<bf16>(M * rE);
+  q.ucls = c.take<bf16>(B * E); q.u_gc = c.take<bf16>(B * E); q.u_gpre = c.take<bf16>(B * E); q.u_gt = c.take<bf16>(B * E);
+  q.s_x = c.take<bf16>(L * M * E); q.s_qkv = c.take<bf16>(L * M * 3 * E); q.s_xmid = c.take<bf16>(L * M * E); q.s_h = c.take<bf16>(L * M * rE);
+  q.s_xcls = c.take<bf16>(B * E); q.tmp = c.take<bf16>(M * E);
+  return c.off;
+}
+// The penalty needs the full-row kernels' shapes (E = 384 or 512, rows in whole units of 16) and bf16 attention; -3 otherwise
+static int pen_shape_ok(const VgVitNet* net, int B) {
+  const VgVitDims& d = net->d;
+  const int S = (d.IH / d.P) * (d.IH / d.P) + 1;
+  return !net->attn_fp8 && vit_row_nwg(d, B * S) > 0 && (B * d.E) % 8 == 0 && ((long long)d.C * d.IH * d.IH) % 4 == 0;
+}
+extern "C" long long vg_vit_penalty_ws_bytes(const VgVitDims* d, int B) {
+  VgVitLayout lay;
+  if (!d || B < 1 || vg_vit_layout(d, &lay)) return -1;
+  PenWs q;
+  return carve_pen(*d, B, nullptr, q);
+}
+extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, const void* fake, const float* eps, float weight, void* ws,
+                              void* ws_pen, float* penalty_out, void* stream) {
+  if (!net0 || !real || !fake || !eps || !ws || !ws_pen || !penalty_out || B < 1 || !net0->G) return -1;
+  if (!pen_shape_ok(net0, B)) return -3;
+  VgVitNet net_ = *net0;
+  net_.dense_top = 1; net_.ctx = nullptr;
+  const VgVitNet* net = &net_;
+  const VgVitDims& d = net->d;
+  VgVitLayout lay;
+  VG_TRY(vg_vit_layout(&d, &lay));
+  hipStream_t st = (hipStream_t)stream;
+  const int E = d.E, NP = (d.IH / d.P) * (d.IH / d.P), S = NP + 1, M = B * S, Kp = d.C * d.P * d.P, rE = d.R * E, HE = E / d.H, L = d.L;
+  const float scale = 1.0f / sqrtf((float)HE);
+  VitWs w; carve_vit(d, B, ws, w);
+  PenWs q; carve_pen(d, B, ws_pen, q);
+  const float* P = net->P; const bf16* Pb = (const bf16*)net->Pb; float* G = net->G;
+  const size_t ME = (size_t)M * E, MR = (size_t)M * rE;
+  const Drop dr = mk_drop(net->dropout_p, net->dropout_seed, net->dropout_step);
+  const bool drop = dr.thr != 0;
+  const int top = L - 1;
+
+  // ---- 1. forward of the interpolated images ----
+  VG_TRY(vg_pen_interp_launch((const bf16*)real, (const bf16*)fake, eps, q.xhat, B, (long long)d.C * d.IH * d.IH, st));
+  VG_TRY(vit_forward_impl(net, B, q.xhat, 0, ws, q.logits, stream, q.h));
+
+  // ---- 2. first backward: d sum(logits) / d x^, every intermediate kept ----
+  VG_TRY(vg_fill_f32_launch(q.ones, (long long)B * d.Kc, 1.0f, st));
+  { const int r = vg_head_bwd_launch(q.ones, P + lay.hw2, w.th, w.dzh, nullptr, nullptr, B, E, d.Kc, 0, st); if (r < 0) return -r; }  // g_pre
+  VG_TRY(lin_dgrad(w.dzh, Pb + lay.hw1, w.dhcls, B, E, E, 0, nullptr, nullptr, 0.f, st));                                                  // g_c
+  VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
+  VG_TRY(vg_scatter_cls_launch(w.dxcls, q.gin + (size_t)top * ME, B, S, E, st, drop ? q.gm2 + (size_t)top * ME : nullptr, dr.thr, site_key(dr, 2 + 2 * top),
+                               dr.scale, dr.step));
+  for (int l = top; l >= 0; --l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* gin = q.gin + (size_t)l * ME;
+    const bf16* gb2 = drop ? q.gm2 + (size_t)l * ME : gin;
+    bf16 *da1 = q.da1 + (size_t)l * MR, *dz1 = q.dz1 + (size_t)l * MR, *dxn2 = q.dxn2 + (size_t)l * ME, *gmid = q.gmid + (size_t)l * ME;
+    bf16 *gm1 = q.gm1 + (size_t)l * ME, *dao = q.dao + (size_t)l * ME, *dqkv = q.dqkv + (size_t)l * ME * 3, *dxn1 = q.dxn1 + (size_t)l * ME;
+    VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, da1, M, E, rE, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, nullptr, dz1, nullptr, (long long)MR, 1, 1, st));
+    VG_TRY(lin_dgrad(dz1, Pb + lo + lay.w1, dxn2, M, rE, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_ln_bwd_launch(dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid, w.part, M, E,
+                            drop ? gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    VG_TRY(lin_dgrad(drop ? gm1 : gmid, Pb + lo + lay.wo, dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
+    VG_TRY(vg_attn_bwd_launch(w.qkv + (size_t)l * ME * 3, w.ao + (size_t)l * ME, dao, w.lse + (size_t)l * B * d.H * S, dqkv, B, d.H, S, HE, scale, 0, st));
+    VG_TRY(lin_dgrad(dqkv, Pb + lo + lay.wqkv, dxn1, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+    bf16* gx = l > 0 ? q.gin + (size_t)(l - 1) * ME : q.g0;
+    bf16* gxm = l > 0 ? q.gm2 + (size_t)(l - 1) * ME : q.g0m;
+    VG_TRY(vg_ln_bwd_launch(dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx, w.part, M, E,
+                            drop ? gxm : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+  }
+  VG_TRY(vg_take_rows_launch(drop ? q.g0m : q.g0, w.gp, B, S, 1, NP, E, st));
+  VG_TRY(lin_dgrad(w.gp, Pb + lay.conv_w, w.dA, B * NP, E, Kp, 0, nullptr, nullptr, 0.f, st));  // = the image gradient, patch by patch
+
+  // ---- 3. the penalty and the direction of the second backward ----
+  VG_TRY(vg_pen_norm_launch(w.dA, q.u_dA, q.pen_img, penalty_out, B, (long long)NP * Kp, weight, st));
+
+  // ---- 4. backward of pass 2, bottom to top ----
+  VgFoldJobs folds; folds.n = 0;
+  const int bbparts = vg_ln_bwd_bwd_nparts(M);
+  {  // patch embedding: d A = gp Wc  ->  u_gp = u_dA Wc^T (rows back behind the CLS rows, embedding dropout's mask), dWc += gp^T u_dA
+    VG_CHECK_HIP(hipMemsetAsync(q.u_x[0], 0, ME * sizeof(bf16), st));
+    VgGemmProb p = mk(q.u_dA, Kp, Pb + lay.conv_w, Kp, B * NP, E, Kp);
+    p.C = q.u_x[0]; p.ldc = E; p.row_in_per = NP; p.row_out_per = S; p.row_out_off = 1;
+    set_drop(p, dr, 0, 1);
+    VG_TRY(vg_gemm_launch(&p, 1, VG_NT, st));
+    const int splits = pick_splits(tiles128(E, Kp), B * NP, EMB_SPLIT_CAP);
+    VgGemmProb pw = wg(w.gp, E, q.u_dA, Kp, B * NP, w.slab, (long long)E * Kp, splits);
+    VG_TRY(vg_gemm_launch(&pw, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * Kp, pw.splits, G + lay.conv_w, (long long)E * Kp, 1, st));
+  }
+  int cur = 0;
+  for (int l = 0; l < L; ++l) {
+    const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* gb2 = drop ? q.gm2 + (size_t)l * ME : q.gin + (size_t)l * ME;
+    const bf16* gb1 = drop ? q.gm1 + (size_t)l * ME : q.gmid + (size_t)l * ME;
+    const bf16 *da1 = q.da1 + (size_t)l * MR, *dz1 = q.dz1 + (size_t)l * MR, *dxn2 = q.dxn2 + (size_t)l * ME;
+    const bf16 *dao = q.dao + (size_t)l * ME, *dqkv = q.dqkv + (size_t)l * ME * 3, *dxn1 = q.dxn1 + (size_t)l * ME;
+    const bf16* u_gx = q.u_x[cur];
+    bf16* u_up = q.u_x[cur ^ 1];
+    float* pb1 = q.pbb + (size_t)(2 * l) * bbparts * E;
+    float* pb2 = q.pbb + (size_t)(2 * l + 1) * bbparts * E;
+    // gX = gmid + LN1'(dxn1; X): the norm's double backward; u reaches gmid unchanged (added below)
+    VG_TRY(vg_ln_bwd_bwd_launch(u_gx, dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, q.u_dxn,
+                                q.s_x + (size_t)l * ME, pb1, M, E, st));
+    VG_TRY(vg_fold_push(folds, pb1, bbparts, E, G + lo + lay.ln1_w, E, nullptr, 0, nullptr, 0, nullptr, 0));
+    VgGemmProb pr[4];
+    const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
+    int sp = pick_splits(tiles, M, VIT_SPLIT_CAP);
+    if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
+      sp = pick_splits384(tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn), M, VIT_SPLIT_CAP);
+    // dxn1 = dqkv Wqkv
+    VG_TRY(lin_fwd(q.u_dxn, E, Pb + lo + lay.wqkv, nullptr, q.u_dqkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    pr[0] = wg(dqkv, 3 * E, q.u_dxn, E, M, w.slab + lay.wqkv, lay.layer_weights, sp);
+    // the four weight gradients of a block share one launch, so each tangent operand keeps a buffer of its own until then
+    // dqkv = attention'(dao; qkv)
+    VG_TRY(vg_attn_bwd_bwd_launch(w.qkv + (size_t)l * ME * 3, dao, w.lse + (size_t)l * B * d.H * S, q.u_dqkv, q.u_dao, q.s_qkv + (size_t)l * ME * 3, B, d.H, S, HE,
+                                  scale, st));
+    // dao = gb1 Wo ; gb1 = mask1 gmid  ->  u_gmid = u_gX + mask1 (u_dao Wo^T)
+    VG_TRY(lin_fwd(q.u_dao, E, Pb + lo + lay.wo, nullptr, q.u_gmid, M, E, VG_ACT_NONE, 0.f, u_gx, nullptr, nullptr, st, &dr, 1 + 2 * l));
+    pr[1] = wg(gb1, E, q.u_dao, E, M, w.slab + lay.wo, lay.layer_weights, sp);
+    // gmid = gin + LN2'(dxn2; x_mid)
+    VG_TRY(vg_ln_bwd_bwd_launch(q.u_gmid, dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, q.u_dxn2,
+                                q.s_xmid + (size_t)l * ME, pb2, M, E, st));
+    VG_TRY(vg_fold_push(folds, pb2, bbparts, E, G + lo + lay.ln2_w, E, nullptr, 0, nullptr, 0, nullptr, 0));
+    // dxn2 = dz1 W1
+    VG_TRY(lin_fwd(q.u_dxn2, E, Pb + lo + lay.w1, nullptr, q.u_dz1, M, rE, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    pr[2] = wg(dz1, rE, q.u_dxn2, E, M, w.slab + lay.w1, lay.layer_weights, sp);
+    // dz1 = da1 gelu'(h)
+    VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, q.u_dz1, q.u_da1, q.s_h + (size_t)l * MR, (long long)MR, 1, 2, st));
+    // da1 = gb2 W2 ; gb2 = mask2 gin  ->  u_gin = u_gmid + mask2 (u_da1 W2^T)
+    VG_TRY(lin_fwd(q.u_da1, rE, Pb + lo + lay.w2, nullptr, u_up, M, E, VG_ACT_NONE, 0.f, q.u_gmid, nullptr, nullptr, st, &dr, 2 + 2 * l));
+    pr[3] = wg(gb2, E, q.u_da1, rE, M, w.slab + lay.w2, lay.layer_weights, sp);
+    VG_TRY(vg_gemm_launch(pr, 4, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+    cur ^= 1;
+  }
+  {  // final LayerNorm on the CLS rows and the classifier head
+    float* pbf = q.pbb + (size_t)(2 * L) * bbparts * E;
+    VG_TRY(vg_take_rows_launch(q.u_x[cur], q.ucls, B, S, 0, 1, E, st));
+    VG_TRY(vg_take_rows_launch(w.X + (size_t)L * ME, q.xcls, B, S, 0, 1, E, st));
+    VG_TRY(vg_ln_bwd_bwd_launch(q.ucls, w.dhcls, q.xcls, w.meanf, w.rstdf, P + lay.lnf_w, q.u_gc, q.s_xcls, pbf, B, E, st));
+    VG_TRY(vg_fold_push(folds, pbf, vg_ln_bwd_bwd_nparts(B), E, G + lay.lnf_w, E, nullptr, 0, nullptr, 0, nullptr, 0));
+    VG_TRY(lin_fwd(q.u_gc, E, Pb + lay.hw1, nullptr, q.u_gpre, B, E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));  // g_c = g_pre Wh1
+    VgGemmProb p = wg(w.dzh, E, q.u_gc, E, B, w.slab, (long long)E * E, B >= 512 ? 4 : (B >= 256 ? 2 : 1));
+    VG_TRY(vg_gemm_launch(&p, 1, VG_TN, st));
+    VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * E, p.splits, G + lay.hw1, (long long)E * E, 1, st));
+    // g_pre = g_t tanh'(p): u_gt (its batch sum is every row of dWh2) and dL/dp, which the second backward starts from (in w.dzh)
+    VG_TRY(vg_pen_head2_launch(q.u_gpre, w.th, P + lay.hw2, q.u_gt, w.dzh, B, E, d.Kc, st));
+    for (int k = 0; k < d.Kc; ++k) VG_TRY(vg_colsum_bf16_launch(q.u_gt, E, B, E, w.part_cs, G + lay.hw2 + (long long)k * E, 1, st));
+  }
+  VG_TRY(vg_colsum_f32_multi_launch(folds, st));
+
+  // ---- 5. the ordinary backward of pass 1 under the injected gradients ----
+  VitInject inj = {};
+  inj.preact = q.h; inj.head_given = 1; inj.s_xcls = q.s_xcls; inj.s_h = q.s_h; inj.s_xmid = q.s_xmid; inj.s_qkv = q.s_qkv; inj.s_x = q.s_x; inj.tmp = q.tmp;
+  return vit_backward_impl(net, B, ws, q.ones, nullptr, 1, 0, L + 2, stream, &inj);
 }
 
 // =============================================================================================

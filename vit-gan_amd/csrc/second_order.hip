@@ -261,3 +261,117 @@ int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, c
   return (int)hipGetLastError();
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small kernels of the gradient penalty as ONE C call (vg_vit_penalty, engine.hip; reference: src/v2/utils.py:124-144).
+// ---------------------------------------------------------------------------------------------------------------------
+// interpolated = eps * real + (1 - eps) * fake, fp32 like the reference forms it (utils.py:130); eps [B]
+__global__ __launch_bounds__(256) void vg_pen_interp_kernel(const bf16* __restrict__ real, const bf16* __restrict__ fake, const float* __restrict__ eps,
+                                                            float* __restrict__ out, long long per, long long n) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const float e = eps[i4 / per], f = 1.0f - e;
+  const bf16x4 r = *(const bf16x4*)(real + i4), k = *(const bf16x4*)(fake + i4);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(e, vg_bf2f(r[j])), __fmul_rn(f, vg_bf2f(k[j])));
+  *(f32x4*)(out + i4) = o;
+}
+int vg_pen_interp_launch(const bf16* real, const bf16* fake, const float* eps, float* out, int B, long long per, hipStream_t st) {
+  if (B < 1 || per < 4 || (per & 3)) return -3;
+  const long long n = (long long)B * per;
+  hipLaunchKernelGGL(vg_pen_interp_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, real, fake, eps, out, per, n);
+  return (int)hipGetLastError();
+}
+// One workgroup per image: n_b = ||g_b||_2 over the image's `per` gradient elements (the patch rows of d A - the same numbers as the
+// image gradient, permuted), pen_img[b] = (n_b - 1)^2 / B, and the direction the second backward starts from,
+// u_b = coef (n_b - 1) / n_b g_b = d(weight * mean_b (n_b - 1)^2) / d g_b with coef = 2 weight / B  (utils.py:143-144).
+__global__ __launch_bounds__(256) void vg_pen_norm_kernel(const bf16* __restrict__ g, bf16* __restrict__ u, float* __restrict__ pen_img, long long per,
+                                                          float coef, float inv_b) {
+  __shared__ float red[4];
+  __shared__ float fac;
+  const bf16* gb = g + (size_t)blockIdx.x * per;
+  bf16* ub = u + (size_t)blockIdx.x * per;
+  float a = 0.f;
+  for (long long i = (long long)threadIdx.x * 4; i < per; i += 1024) {
+    const bf16x4 v = *(const bf16x4*)(gb + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float x = vg_bf2f(v[j]); a = fmaf(x, x, a); }
+  }
+  a = vg_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nb = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    pen_img[blockIdx.x] = (nb - 1.0f) * (nb - 1.0f) * inv_b;
+    fac = nb > 0.f ? coef * (nb - 1.0f) / nb : 0.f;  // (torch's norm has the zero subgradient at 0)
+  }
+  __syncthreads();
+  const float f = fac;
+  for (long long i = (long long)threadIdx.x * 4; i < per; i += 1024) {
+    const bf16x4 v = *(const bf16x4*)(gb + i);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = vg_f2bf(f * vg_bf2f(v[j]));
+    *(bf16x4*)(ub + i) = o;
+  }
+}
+__global__ __launch_bounds__(256) void vg_pen_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  a = vg_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int vg_pen_norm_launch(const bf16* g, bf16* u, float* pen_img, float* pen_out, int B, long long per, float weight, hipStream_t st) {
+  if (B < 1 || per < 4 || (per & 3)) return -3;
+  hipLaunchKernelGGL(vg_pen_norm_kernel, dim3(B), dim3(256), 0, st, g, u, pen_img, per, 2.0f * weight / (float)B, 1.0f / (float)B);
+  hipLaunchKernelGGL(vg_pen_sum_kernel, dim3(1), dim3(256), 0, st, pen_img, B, pen_out);
+  return (int)hipGetLastError();
+}
+// Classifier head, second order: the first backward is g_pre = g_t (1 - t^2) with g_t[e] = sum_k W2[k, e] (grad_outputs = ones) and t = tanh(p).
+// Given u = dL/d g_pre:  u_gt = u (1 - t^2)  (its batch sum is dL/dW2[k, :], every k)  and  s_p = u g_t (-2 t (1 - t^2)) = dL/dp.
+__global__ __launch_bounds__(256) void vg_pen_head2_kernel(const bf16* __restrict__ u, const bf16* __restrict__ t, const float* __restrict__ W2,
+                                                           bf16* __restrict__ u_gt, bf16* __restrict__ s_p, int B, int E, int Kc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * E) return;
+  const int e = (int)(i % E);
+  float gt = 0.f;
+  for (int k = 0; k < Kc; ++k) gt += W2[(size_t)k * E + e];
+  gt = vg_bf2f(vg_f2bf(gt));  // (the operator chain hands g_t on as a bf16 tensor)
+  const float tv = vg_bf2f(t[i]), uv = vg_bf2f(u[i]);
+  const float d1 = 1.0f - tv * tv;
+  u_gt[i] = vg_f2bf(uv * d1);
+  s_p[i] = vg_f2bf(uv * gt * (-2.0f * tv * d1));
+}
+int vg_pen_head2_launch(const bf16* u, const bf16* t, const float* W2, bf16* u_gt, bf16* s_p, int B, int E, int Kc, hipStream_t st) {
+  if (B < 1 || E < 1 || Kc < 1) return -3;
+  hipLaunchKernelGGL(vg_pen_head2_kernel, dim3((unsigned)(((long long)B * E + 255) / 256)), dim3(256), 0, st, u, t, W2, u_gt, s_p, B, E, Kc);
+  return (int)hipGetLastError();
+}
+// out = a + b (one rounding; out may alias a): where the second backward meets a gradient the double backward injected
+__global__ __launch_bounds__(256) void vg_add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, long long n) {
+  const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i8 >= n) return;
+  const bf16x8 x = *(const bf16x8*)(a + i8), y = *(const bf16x8*)(b + i8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = vg_f2bf(vg_bf2f(x[j]) + vg_bf2f(y[j]));
+  *(bf16x8*)(out + i8) = o;
+}
+int vg_add_bf16_launch(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t st) {
+  if (n < 8 || (n & 7)) return -3;
+  hipLaunchKernelGGL(vg_add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, a, b, out, n);
+  return (int)hipGetLastError();
+}
+__global__ __launch_bounds__(256) void vg_fill_f32_kernel(float* __restrict__ p, long long n, float v) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int vg_fill_f32_launch(float* p, long long n, float v, hipStream_t st) {
+  if (n < 1) return -3;
+  hipLaunchKernelGGL(vg_fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  return (int)hipGetLastError();
+}

@@ -97,3 +97,9 @@ int vg_attn_bwd_bwd_launch(const bf16* qkv, const bf16* d_o, const float* lse, c
 int vg_grad_clip_launch(float* g, long long n, float gscale, float max_norm, float* scratch, hipStream_t st);
 int vg_add_table_launch(bf16* x, const float* table, long long rows, int E, int period, hipStream_t st);
 int vg_diversity_launch(const bf16* x, bf16* d_img, float* loss_out, float* scratch, int B, int D, float weight, hipStream_t st);
+// the gradient penalty as one C call (vg_vit_penalty): its small kernels (second_order.hip)
+int vg_pen_interp_launch(const bf16* real, const bf16* fake, const float* eps, float* out, int B, long long per, hipStream_t st);
+int vg_pen_norm_launch(const bf16* g, bf16* u, float* pen_img, float* pen_out, int B, long long per, float weight, hipStream_t st);
+int vg_pen_head2_launch(const bf16* u, const bf16* t, const float* W2, bf16* u_gt, bf16* s_p, int B, int E, int Kc, hipStream_t st);
+int vg_add_bf16_launch(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t st);
+int vg_fill_f32_launch(float* p, long long n, float v, hipStream_t st);

@@ -44,7 +44,7 @@ class GanEngine:
                  diversity_weight: float = 0.0, instance_noise: float = 0.0,
                  process_group: Optional["dist.ProcessGroup"] = None, external_noise: bool = False,
                  two_stream: bool = False, compress_mapping_grad: bool = False, shard_mapping_update: bool = False, gp_weight: float = 0.0,
-                 exchange_single_rank: bool = False, dense_top_block: bool = False):
+                 exchange_single_rank: bool = False, dense_top_block: bool = False, gp_autograd: bool = False):
         """concurrent_wgrad: the discriminator's weight gradients on a side stream beside its input gradients.  Off by default
         since the persistent GEMMs (csrc/gemm_wr.hip, gemm_tn.hip: their workgroups hold the CUs for a whole launch) - the
         side stream measured 6.70 against 6.67 ms/step.
@@ -60,7 +60,11 @@ class GanEngine:
         two chains are in different phases (a GEMM main loop next to another GEMM's epilogue, a LayerNorm next to a
         GEMM), which the single-chain step cannot be: every launch of this model covers the chip about once.
         gp_weight: weight of the WGAN-GP gradient penalty in the discriminator loss (``c.lambda_gp`` of training.py:106; the
-        field is missing from the reference's Config).  The penalty runs through torch autograd over the twice-
+        field is missing from the reference's Config).  Where the full-row kernels take the network (E 384 / 512, B * tokens a
+        multiple of 16, bf16 attention) the penalty is ONE C call, ``vg_vit_penalty``: forward, input-gradient backward, its
+        double backward and the second backward as kernel sequences with the engine's counter-based dropout masks (the
+        discriminator is in train mode there, as in the reference); ``gp_autograd=True`` - and every other shape - takes the
+        operator-set path below, the form the C call is tested against.  That path runs through torch autograd over the twice-
         differentiable operator set (penalty.py) on the discriminator's real / fake inputs of this step and accumulates
         into the same gradient buffer before the exchange and AdamW.  With ``use_graph`` the autograd passes are captured with
         the rest of the step (every operator is an enqueue-only kernel call; epsilon and the penalty pass's dropout masks come
@@ -119,6 +123,10 @@ class GanEngine:
             # the penalty path (ops2.py) differentiates the bf16 attention kernels: with fp8 operands in the trained network
             # it would penalise a slightly different function than the one being trained
             raise ValueError("gp_weight: the gradient penalty is built on the bf16 attention kernels; switch attention_fp8 off")
+        d_ = vit._dims
+        tokens = (d_.IH // d_.P) ** 2 + 1
+        self.gp_c_call = (self.gp_w != 0.0 and not gp_autograd and d_.E in (384, 512) and (int(batch) * tokens) % 16 == 0
+                          and not bool(getattr(vit, "attention_fp8", False)))
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
@@ -151,6 +159,9 @@ class GanEngine:
             self.ws_d2 = torch.empty(L.vg_vit_ws_bytes(C.byref(d), B), dtype=torch.uint8, device=dev)
             self.grad2 = torch.zeros_like(vit._flat.grad)
             self.side = torch.cuda.Stream(device=dev)
+        if self.gp_c_call:  # the penalty's own passes: its forward runs in ws_d (the step's passes come after it), the rest here
+            self.ws_gp = torch.empty(L.vg_vit_penalty_ws_bytes(C.byref(d), B), dtype=torch.uint8, device=dev)
+            self.gp_eps = torch.empty(B, dtype=torch.float32, device=dev)
         self.ws_g = torch.empty(L.vg_gen_ws_bytes(C.byref(g), B), dtype=torch.uint8, device=dev)
         self.imgs = torch.empty(2 * B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)  # [real ; fake]
         self.dfake = torch.empty(B, d.C, d.IH, d.IH, dtype=torch.bfloat16, device=dev)
@@ -422,7 +433,16 @@ class GanEngine:
             torch.add(self.imgs.float(), self.inoise, alpha=self.inst_sigma, out=self.inoise)
             self.imgs_noisy.copy_(self.inoise)
             d_in = self.imgs_noisy
-        if self.gp_w != 0.0:  # gradient_penalty(D, noisy_real, noisy_fake) joins the D loss (training.py:101-106)
+        if self.gp_c_call:  # gradient_penalty(D, noisy_real, noisy_fake) joins the D loss (training.py:101-106): one C call
+            if self.gp_epsilon is not None:
+                self.gp_eps.copy_(self.gp_epsilon.reshape(-1))
+            else:
+                self.gp_eps.uniform_()  # epsilon = torch.rand(B, 1, 1, 1), utils.py:129
+            pnet = _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(), self.p_d, self.seed * 8 + 3,
+                                 self.step_t.data_ptr(), None, 0, 1)
+            _lib.check(L.vg_vit_penalty(C.byref(pnet), B, _p(d_in), C.c_void_p(d_in.data_ptr() + B * img_bytes), _p(self.gp_eps), self.gp_w,
+                                        _p(self.ws_d), _p(self.ws_gp), _p(self.gp_loss), st), "vg_vit_penalty")
+        elif self.gp_w != 0.0:
             from .penalty import gradient_penalty
             fd.attach_grads()
             disc = self.vit
