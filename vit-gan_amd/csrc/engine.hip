@@ -779,7 +779,7 @@ extern "C" int vg_vit_backward(const VgVitNet* net, int B, void* ws, const float
 struct PenWs {
   float *xhat, *ones, *logits, *pen_img, *pbb;
   bf16 *h, *gin, *gm2, *da1, *dz1, *dxn2, *gmid, *gm1, *dao, *dqkv, *dxn1, *g0, *g0m, *xcls;
-  bf16 *u_dA, *u_x[2], *u_dxn, *u_dxn2, *u_dqkv, *u_dao, *u_gmid, *u_dz1, *u_da1, *ucls, *u_gc, *u_gpre, *u_gt;
+  bf16 *u_dA, *u_x[2], *u_dxn[2], *u_dxn2[2], *u_dqkv, *u_dao[2], *u_gmid, *u_dz1, *u_da1[2], *ucls, *u_gc, *u_gpre, *u_gt;  // [2]: operands of a PAIR of blocks' weight gradients
   bf16 *s_x, *s_qkv, *s_xmid, *s_h, *s_xcls, *tmp;
 };
 static long long carve_pen(const VgVitDims& d, int B, void* base, PenWs& q) {
@@ -797,8 +797,10 @@ static long long carve_pen(const VgVitDims& d, int B, void* base, PenWs& q) {
   q.g0 = c.take<bf16>(M * E); q.g0m = c.take<bf16>(M * E); q.xcls = c.take<bf16>(B * E);
   q.u_dA = c.take<bf16>(B * NP * Kp);
   q.u_x[0] = c.take<bf16>(M * E); q.u_x[1] = c.take<bf16>(M * E);
-  q.u_dxn = c.take<bf16>(M * E); q.u_dxn2 = c.take<bf16>(M * E); q.u_dqkv = c.take<bf16>(M * 3 * E); q.u_dao = c.take<bf16>(M * E); q.u_gmid = c.take<bf16>(M * E);
-  q.u_dz1 = c.take<bf16>(M * rE); q.u_da1 = c.take<bf16>(M * rE);
+  for (int i = 0; i < 2; ++i) {
+    q.u_dxn[i] = c.take<bf16>(M * E); q.u_dxn2[i] = c.take<bf16>(M * E); q.u_dao[i] = c.take<bf16>(M * E); q.u_da1[i] = c.take<bf16>(M * rE);
+  }
+  q.u_dqkv = c.take<bf16>(M * 3 * E); q.u_gmid = c.take<bf16>(M * E); q.u_dz1 = c.take<bf16>(M * rE);
   q.ucls = c.take<bf16>(B * E); q.u_gc = c.take<bf16>(B * E); q.u_gpre = c.take<bf16>(B * E); q.u_gt = c.take<bf16>(B * E);
   q.s_x = c.take<bf16>(L * M * E); q.s_qkv = c.take<bf16>(L * M * 3 * E); q.s_xmid = c.take<bf16>(L * M * E); q.s_h = c.take<bf16>(L * M * rE);
   q.s_xcls = c.take<bf16>(B * E); q.tmp = c.take<bf16>(M * E);
@@ -888,6 +890,14 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
     VG_TRY(vg_slab_reduce_launch(w.slab, (long long)E * Kp, pw.splits, G + lay.conv_w, (long long)E * Kp, 1, st));
   }
   int cur = 0;
+  // the weight gradients dW += dY^T ddX of TWO blocks go out as one grouped split-K launch + one fold (half the K slices each: half the slab
+  // traffic per unit of work, like the engine's own backward), so the tangent operands of a block live in one of two buffer sets
+  const long long wtiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
+  int sp = pick_splits(wtiles * 2, M, VIT_SPLIT_CAP / 2);
+  if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
+    sp = pick_splits384(2 * (tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn)), M, VIT_SPLIT_CAP / 2);
+  VgGemmProb pr[8];
+  int npr = 0;
   for (int l = 0; l < L; ++l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
     const bf16* gb2 = drop ? q.gm2 + (size_t)l * ME : q.gin + (size_t)l * ME;
@@ -896,41 +906,45 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
     const bf16 *dao = q.dao + (size_t)l * ME, *dqkv = q.dqkv + (size_t)l * ME * 3, *dxn1 = q.dxn1 + (size_t)l * ME;
     const bf16* u_gx = q.u_x[cur];
     bf16* u_up = q.u_x[cur ^ 1];
+    const int ps = l & 1;  // operand set, and this block's half of the slab
+    bf16 *u_dxn = q.u_dxn[ps], *u_dxn2 = q.u_dxn2[ps], *u_dao = q.u_dao[ps], *u_da1 = q.u_da1[ps];
+    float* slab = w.slab + (size_t)ps * sp * lay.layer_weights;
     float* pb1 = q.pbb + (size_t)(2 * l) * bbparts * E;
     float* pb2 = q.pbb + (size_t)(2 * l + 1) * bbparts * E;
     // gX = gmid + LN1'(dxn1; X): the norm's double backward; u reaches gmid unchanged (added below)
-    VG_TRY(vg_ln_bwd_bwd_launch(u_gx, dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, q.u_dxn,
+    VG_TRY(vg_ln_bwd_bwd_launch(u_gx, dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, u_dxn,
                                 q.s_x + (size_t)l * ME, pb1, M, E, st));
     VG_TRY(vg_fold_push(folds, pb1, bbparts, E, G + lo + lay.ln1_w, E, nullptr, 0, nullptr, 0, nullptr, 0));
-    VgGemmProb pr[4];
-    const long long tiles = tiles128(3 * E, E) + tiles128(E, E) + tiles128(rE, E) + tiles128(E, rE);
-    int sp = pick_splits(tiles, M, VIT_SPLIT_CAP);
-    if (const int bn = wide_bn(E, rE); bn && M % 32 == 0 && E % 128 == 0 && rE % 128 == 0)
-      sp = pick_splits384(tiles_wide(3 * E, E, bn) + tiles_wide(E, E, bn) + tiles_wide(rE, E, bn) + tiles_wide(E, rE, bn), M, VIT_SPLIT_CAP);
     // dxn1 = dqkv Wqkv
-    VG_TRY(lin_fwd(q.u_dxn, E, Pb + lo + lay.wqkv, nullptr, q.u_dqkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    pr[0] = wg(dqkv, 3 * E, q.u_dxn, E, M, w.slab + lay.wqkv, lay.layer_weights, sp);
-    // the four weight gradients of a block share one launch, so each tangent operand keeps a buffer of its own until then
+    VG_TRY(lin_fwd(u_dxn, E, Pb + lo + lay.wqkv, nullptr, q.u_dqkv, M, 3 * E, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    pr[npr++] = wg(dqkv, 3 * E, u_dxn, E, M, slab + lay.wqkv, lay.layer_weights, sp);
     // dqkv = attention'(dao; qkv)
-    VG_TRY(vg_attn_bwd_bwd_launch(w.qkv + (size_t)l * ME * 3, dao, w.lse + (size_t)l * B * d.H * S, q.u_dqkv, q.u_dao, q.s_qkv + (size_t)l * ME * 3, B, d.H, S, HE,
+    VG_TRY(vg_attn_bwd_bwd_launch(w.qkv + (size_t)l * ME * 3, dao, w.lse + (size_t)l * B * d.H * S, q.u_dqkv, u_dao, q.s_qkv + (size_t)l * ME * 3, B, d.H, S, HE,
                                   scale, st));
     // dao = gb1 Wo ; gb1 = mask1 gmid  ->  u_gmid = u_gX + mask1 (u_dao Wo^T)
-    VG_TRY(lin_fwd(q.u_dao, E, Pb + lo + lay.wo, nullptr, q.u_gmid, M, E, VG_ACT_NONE, 0.f, u_gx, nullptr, nullptr, st, &dr, 1 + 2 * l));
-    pr[1] = wg(gb1, E, q.u_dao, E, M, w.slab + lay.wo, lay.layer_weights, sp);
+    VG_TRY(lin_fwd(u_dao, E, Pb + lo + lay.wo, nullptr, q.u_gmid, M, E, VG_ACT_NONE, 0.f, u_gx, nullptr, nullptr, st, &dr, 1 + 2 * l));
+    pr[npr++] = wg(gb1, E, u_dao, E, M, slab + lay.wo, lay.layer_weights, sp);
     // gmid = gin + LN2'(dxn2; x_mid)
-    VG_TRY(vg_ln_bwd_bwd_launch(q.u_gmid, dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, q.u_dxn2,
+    VG_TRY(vg_ln_bwd_bwd_launch(q.u_gmid, dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, u_dxn2,
                                 q.s_xmid + (size_t)l * ME, pb2, M, E, st));
     VG_TRY(vg_fold_push(folds, pb2, bbparts, E, G + lo + lay.ln2_w, E, nullptr, 0, nullptr, 0, nullptr, 0));
     // dxn2 = dz1 W1
-    VG_TRY(lin_fwd(q.u_dxn2, E, Pb + lo + lay.w1, nullptr, q.u_dz1, M, rE, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
-    pr[2] = wg(dz1, rE, q.u_dxn2, E, M, w.slab + lay.w1, lay.layer_weights, sp);
+    VG_TRY(lin_fwd(u_dxn2, E, Pb + lo + lay.w1, nullptr, q.u_dz1, M, rE, VG_ACT_NONE, 0.f, nullptr, nullptr, nullptr, st));
+    pr[npr++] = wg(dz1, rE, u_dxn2, E, M, slab + lay.w1, lay.layer_weights, sp);
     // dz1 = da1 gelu'(h)
-    VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, q.u_dz1, q.u_da1, q.s_h + (size_t)l * MR, (long long)MR, 1, 2, st));
+    VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, q.u_dz1, u_da1, q.s_h + (size_t)l * MR, (long long)MR, 1, 2, st));
     // da1 = gb2 W2 ; gb2 = mask2 gin  ->  u_gin = u_gmid + mask2 (u_da1 W2^T)
-    VG_TRY(lin_fwd(q.u_da1, rE, Pb + lo + lay.w2, nullptr, u_up, M, E, VG_ACT_NONE, 0.f, q.u_gmid, nullptr, nullptr, st, &dr, 2 + 2 * l));
-    pr[3] = wg(gb2, E, q.u_da1, rE, M, w.slab + lay.w2, lay.layer_weights, sp);
-    VG_TRY(vg_gemm_launch(pr, 4, VG_TN, st));
-    VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, pr[0].splits, G + lo, lay.layer_weights, 1, st));
+    VG_TRY(lin_fwd(u_da1, rE, Pb + lo + lay.w2, nullptr, u_up, M, E, VG_ACT_NONE, 0.f, q.u_gmid, nullptr, nullptr, st, &dr, 2 + 2 * l));
+    pr[npr++] = wg(gb2, E, u_da1, rE, M, slab + lay.w2, lay.layer_weights, sp);
+    if (ps == 1 || l == L - 1) {  // the pair (or the odd block out) is complete
+      VG_TRY(vg_gemm_launch(pr, npr, VG_TN, st));
+      const int ns = pr[0].splits;  // (the launcher may lower the slice count; every problem has the same M rows)
+      if (npr == 8)
+        VG_TRY(vg_slab_reduce2_launch(w.slab, w.slab + (size_t)sp * lay.layer_weights, lay.layer_weights, ns, G + lo - lay.layer_stride, G + lo, lay.layer_weights, 1, st));
+      else
+        VG_TRY(vg_slab_reduce_launch(w.slab, lay.layer_weights, ns, G + lo, lay.layer_weights, 1, st));
+      npr = 0;
+    }
     cur ^= 1;
   }
   {  // final LayerNorm on the CLS rows and the classifier head
