@@ -31,6 +31,7 @@ python3 tools/row_bench.py > $OUT/${TAG}_row_bench.txt 2>&1
 python3 tools/step_timeline.py $OUT/ks_default > $OUT/${TAG}_step_timeline.txt 2>&1
 (cd /tmp && prof ks_gp --kernel-trace --stats --output-format csv -d $OUT/ks_gp -- python3 $R/bench.py --loss wasserstein --gp 10 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-workloads --no-roofline)
 f=$(find $OUT/ks_gp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_gp_step_kernel_stats.csv
+python3 tools/step_timeline.py $OUT/ks_gp > $OUT/${TAG}_gp_step_timeline.txt 2>&1
 (python3 tools/micro/blas_cmp.py; python3 tools/gemm_bench.py) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_vendor_gemm_calibration_raw.txt
 python3 -m pytest tests/test_blocks_gpu.py -m gpu -q -s 2>&1 | grep -E "tensors checked|SLN scalars|^ +(sln|transformer_layers|layer_norm)" > $OUT/stage_raw.txt
 # the bench line quotes the two PMC summaries from profiles/ (when their tree hash is this tree's): put this run's there first
