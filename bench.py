@@ -323,7 +323,7 @@ def main():
            "c5": dict(image=128, patch=16, embed=768, heads=12, batch=128, gpatch=16)}
     use_graph = True if args.graph < 0 else bool(args.graph)
 
-    def make(workload, B, fp8_flag):
+    def make(workload, B, fp8_flag, loss=None, gp=None):
         """Discriminator, generator and engine of one workload (random init of that architecture, synthetic data)."""
         geo = GEO[workload]
         torch.manual_seed(0)  # identical init on every rank (v1 config.py:61 seed 0)
@@ -338,10 +338,10 @@ def main():
         else:
             G = SirenGenerator(image_size=geo["image"], embed=geo["embed"], heads=geo["heads"], patch_size=geo["gpatch"],
                                dropout=0.2 if args.dropout else 0.0).to(dev).train()
-        eng = GanEngine(D, G, batch=B, loss=args.loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
+        eng = GanEngine(D, G, batch=B, loss=args.loss if loss is None else loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                         concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
                         compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, shard_mapping_update=bool(args.shard_mapping_update) and world > 1,
-                        gp_weight=args.gp,
+                        gp_weight=args.gp if gp is None else gp,
                         dense_top_block=bool(args.dense_top_block))
         return geo, G, eng, fp8
 
@@ -438,10 +438,16 @@ def main():
             eng.close()
             del eng
             extras = []
-            for wl in ("c4", "c5"):
+            # c4 / c5: BASELINE's larger configurations; c2-wgan-gp: the headline configuration on the reference's Wasserstein step with the
+            # gradient penalty (training.py:67-125, lambda_gp = 10) - SURVEY 8f row f2
+            for wl in ("c4", "c5", "c2-wgan-gp"):
                 try:  # an extra measurement must never cost the headline its line
-                    g2, G2, e2, f8 = make(wl, GEO[wl]["batch"], -1)
-                    B2 = GEO[wl]["batch"]
+                    if wl == "c2-wgan-gp":
+                        g2, G2, e2, f8 = make("c2", B, -1, loss="wasserstein", gp=10.0)
+                        B2 = B
+                    else:
+                        g2, G2, e2, f8 = make(wl, GEO[wl]["batch"], -1)
+                        B2 = GEO[wl]["batch"]
                     gen2 = torch.Generator(device=dev).manual_seed(99)
                     r2 = [torch.rand(B2, 3, g2["image"], g2["image"], device=dev, generator=gen2) * 2 - 1 for _ in range(2)]
                     for i in range(4):
@@ -457,12 +463,18 @@ def main():
                     ms = a0.elapsed_time(a1) / n2
                     fs, fe = step_flops(g2, G2, f8)
                     ips2 = B2 / ms * 1e3
-                    extras.append({"workload": wl, "config": f"BASELINE.json configs[{3 if wl == 'c4' else 4}] geometry on one GPU: {g2['image']}x{g2['image']} patch {g2['patch']}, "
-                                                             f"E={g2['embed']}, {g2['heads']} heads, 6 blocks, patch-grid SLN/SIREN generator, B={B2}",
+                    cfg_txt = (f"BASELINE.json configs[{3 if wl == 'c4' else 4}] geometry on one GPU: {g2['image']}x{g2['image']} patch {g2['patch']}, "
+                               f"E={g2['embed']}, {g2['heads']} heads, 6 blocks, patch-grid SLN/SIREN generator, B={B2}") if wl != "c2-wgan-gp" else (
+                               f"the headline configuration (C2, B={B2}) on the Wasserstein step with the gradient penalty, gp_weight 10 "
+                               f"(penalty as one C call: {bool(e2.gp_c_call)})")
+                    extras.append({"workload": wl, "config": cfg_txt,
                                    "fp8_attention": f8, "steps": n2, "warmup": 4, "ms_per_step": round(ms, 4), "images_per_sec": round(ips2, 1),
                                    "step_tflops": round(ips2 * fs / 1e12, 1), "step_frac_of_peak": round(ips2 * fs / 1e12 / PEAK_BF16_TFLOPS, 4),
                                    "step_frac_of_peak_executed": round(ips2 * fe / 1e12 / PEAK_BF16_TFLOPS, 4), "hip_graph": e2.graph_active,
                                    "losses_finite": all(x == x and abs(x) < 1e4 for x in l2.cpu().tolist())})
+                    if wl == "c2-wgan-gp":  # (no flop count of the penalty's four extra passes is claimed)
+                        for k in ("step_tflops", "step_frac_of_peak", "step_frac_of_peak_executed"):
+                            extras[-1][k] = None
                     e2.close()
                     del e2, G2, r2
                     torch.cuda.empty_cache()
