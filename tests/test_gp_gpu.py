@@ -266,7 +266,7 @@ def _penalty_c_call(D, real, fake, eps, weight, p_drop=0.0, seed=11, step=None):
     return float(out), fl.grad.detach().clone()
 
 
-@pytest.mark.parametrize("B,layers", [(16, 2), (32, 3)])
+@pytest.mark.parametrize("B,layers", [(16, 2), (32, 3), (256, 6)])
 def test_penalty_c_call_matches_the_operator_set(B, layers):
     """vg_vit_penalty (forward, input-gradient backward, its double backward and the second backward as ONE C call) against the
     operator-set form through torch autograd (penalty.gradient_penalty, itself pinned to the reference's fixture above): dropout off,
@@ -341,3 +341,38 @@ def test_penalty_c_call_with_dropout_is_the_gradient_of_its_own_value():
     fd = (vals[0] - vals[1]) / (2 * h)
     print(f"penalty {pen0:.5f}; directional derivative: finite differences {fd:.5e}  |grad|^2 {gn2:.5e}  ratio {fd / gn2:.3f}")
     assert 0.8 < fd / gn2 < 1.25
+
+
+def test_penalty_step_replay_does_not_depend_on_host_synchronisation():
+    """Regression (round 4): the penalty call zero-filled one buffer with hipMemsetAsync.  As a memset node of the step's hipGraph it went
+    wrong once the host had queued about a hundred replays ahead of the device: the replayed step then depended on how often the host
+    synchronised (tools/micro/gp_determinism.py: identical for 80 steps, a different - collapsed - trajectory by step 140; a soak run
+    went non-finite at step 2 700).  The fill is a kernel now.  Full-size configuration (where it showed), 200 replayed steps, a sync
+    after every step against none at all: bit-identical weights (the memset build fails this)."""
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.engine import GanEngine
+    from vit_gan_amd.generator import SirenGenerator
+    from vit_gan_amd.modules import ViTDiscriminator
+    B = 256
+    out = []
+    for sync_every_step in (False, True):
+        torch.manual_seed(0)
+        D = ViTDiscriminator(Config(embeddings_dimension=384, classes_count=1, batch_size=B)).cuda().train()
+        G = SirenGenerator().cuda().train()
+        eng = GanEngine(D, G, batch=B, use_graph=True, loss="wasserstein", gp_weight=10.0, clip_d=5.0, clip_g=0.5)
+        assert eng.gp_c_call
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        reals = [torch.rand(B, 3, 32, 32, device="cuda", generator=gen) * 2 - 1 for _ in range(4)]
+        keep = []
+        for i in range(200):
+            l = eng.step(reals[i % 4])
+            if i % 20 == 0:
+                keep.append(l.clone())  # (ordinary stream work between the replays, as a training loop has)
+            if sync_every_step or i == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        assert eng.graph_active
+        out.append((D.vit._flat.flat.detach().clone(), G._flat.flat.detach().clone(), float(eng.gp_loss)))
+        eng.close()
+    assert torch.isfinite(out[0][0]).all() and out[0][2] > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]

@@ -879,7 +879,7 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
   VgFoldJobs folds; folds.n = 0;
   const int bbparts = vg_ln_bwd_bwd_nparts(M);
   {  // patch embedding: d A = gp Wc  ->  u_gp = u_dA Wc^T (rows back behind the CLS rows, embedding dropout's mask), dWc += gp^T u_dA
-    VG_CHECK_HIP(hipMemsetAsync(q.u_x[0], 0, ME * sizeof(bf16), st));
+    VG_TRY(vg_fill_f32_launch((float*)q.u_x[0], (long long)(ME / 2), 0.0f, st));  // (a kernel, not hipMemsetAsync: see DESIGN 7 - the memset node of a captured graph was not ordered with its neighbours)
     VgGemmProb p = mk(q.u_dA, Kp, Pb + lay.conv_w, Kp, B * NP, E, Kp);
     p.C = q.u_x[0]; p.ldc = E; p.row_in_per = NP; p.row_out_per = S; p.row_out_off = 1;
     set_drop(p, dr, 0, 1);

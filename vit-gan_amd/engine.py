@@ -435,7 +435,7 @@ class GanEngine:
             d_in = self.imgs_noisy
         if self.gp_c_call:  # gradient_penalty(D, noisy_real, noisy_fake) joins the D loss (training.py:101-106): one C call
             if self.gp_epsilon is not None:
-                self.gp_eps.copy_(self.gp_epsilon.reshape(-1))
+                torch.add(self.gp_epsilon.reshape(-1).float(), 0.0, out=self.gp_eps)  # (an elementwise kernel, not a D2D copy: no memcpy / memset nodes in the captured step)
             else:
                 self.gp_eps.uniform_()  # epsilon = torch.rand(B, 1, 1, 1), utils.py:129
             pnet = _lib.VgVitNet(self.vit._dims, fd.flat.data_ptr(), fd.shadow.data_ptr(), fd.grad.data_ptr(), self.p_d, self.seed * 8 + 3,
