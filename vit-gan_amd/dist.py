@@ -114,7 +114,7 @@ class GradSync:
             if native:
                 out = torch.empty(b - a, dtype=flat.dtype, device=flat.device)
                 dist.reduce_scatter_tensor(out, view, op=dist.ReduceOp.SUM, group=self.group)
-                flat[a:b].copy_(out)
+                torch.mul(out, 1, out=flat[a:b])  # (an elementwise kernel, not a D2D copy: the captured step carries no memcpy / memset nodes - DESIGN 7, hardening)
             else:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         if not self.overlap:
@@ -134,7 +134,7 @@ class GradSync:
         view = buf[lo:hi]
 
         def run():
-            mine = buf[a:b].clone()  # (the collective's input must not alias its output)
+            mine = torch.mul(buf[a:b], 1)  # the collective's input must not alias its output (a kernel, not clone(): see reduce_scatter_range)
             if dist.get_backend(self.group) == "nccl":
                 dist.all_gather_into_tensor(view, mine, group=self.group)
             else:
