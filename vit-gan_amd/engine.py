@@ -16,6 +16,7 @@ Nothing synchronises with the host; with ``use_graph`` the whole step is replaye
 from __future__ import annotations
 
 import ctypes as C
+import time
 import warnings
 import weakref
 from typing import Optional
@@ -536,8 +537,18 @@ class GanEngine:
             for t, keep in zip(self._state_tensors(), saved):
                 t.copy_(keep)
             graph = torch.cuda.CUDAGraph()
+            # With a process group the RCCL watchdog THREAD polls the events of the collectives the warm-up step enqueued: under the default
+            # ("global") capture mode such a hipEventQuery from another thread while this one captures is an error that invalidates the
+            # capture and, raised inside the watchdog, ends the process (seen once in ~10 runs of the one-rank RCCL test).  "thread_local"
+            # confines the restriction to the capturing thread, which is what a captured step with collectives needs.
+            mode = "thread_local" if self.sync.active else "global"
+            if self.sync.active:
+                # ... and the watchdog gets the time to retire the warm-up's (finished) collectives from its list - it polls every 100 ms,
+                # and collectives enqueued DURING a capture are never put on that list - so that it has nothing to query while we capture
+                torch.cuda.synchronize()
+                time.sleep(0.5)
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     self._enqueue_body()
             except Exception as exc:  # only reachable with collectives or the autograd-driven penalty in the step: otherwise it is all our own enqueue-only calls
                 if not self.sync.active and self.gp_w == 0.0:
