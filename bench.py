@@ -280,6 +280,10 @@ def main():
                          "persistent weights-in-registers GEMMs: their workgroups hold the CUs for a whole launch, and the side stream "
                          "measured 6.70 vs 6.67 ms/step)")
     ap.add_argument("--roofline-only", action="store_true", help="profiling aid: run only the dominant-kernel timing leg and print its object")
+    ap.add_argument("--rehearse-exchange", type=int, default=0,
+                    help="1 (with --gpus 1): run the multi-GPU code path of this file on ONE rank - a one-rank RCCL group, the gradient exchange calls "
+                         "executed (identity collectives) and captured in the step's hipGraph, the barriers and the MAX all-reduce of the timing; "
+                         "what a one-GPU box can rehearse of the driver's N > 1 run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the default and the measured path); gloo only to rehearse the multi-rank code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices: local_rank %% device_count)")
@@ -310,8 +314,10 @@ def main():
     if args.backend == "gloo":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    dp = world > 1 or (bool(args.rehearse_exchange) and world == 1)  # a process group exists: barriers, exchanged gradients, MAX over ranks
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -340,8 +346,8 @@ def main():
                                dropout=0.2 if args.dropout else 0.0).to(dev).train()
         eng = GanEngine(D, G, batch=B, loss=args.loss if loss is None else loss, fuse_real_fake=not args.no_fuse, use_graph=use_graph, seed=1000 + rank,
                         concurrent_wgrad=bool(args.concurrent_wgrad) and not args.single_stream, two_stream=bool(args.two_stream) and world == 1,
-                        compress_mapping_grad=bool(args.compress_mapping_grad) and world > 1, shard_mapping_update=bool(args.shard_mapping_update) and world > 1,
-                        gp_weight=args.gp if gp is None else gp,
+                        compress_mapping_grad=bool(args.compress_mapping_grad) and dp, shard_mapping_update=bool(args.shard_mapping_update) and dp,
+                        gp_weight=args.gp if gp is None else gp, exchange_single_rank=bool(args.rehearse_exchange) and world == 1,
                         dense_top_block=bool(args.dense_top_block))
         return geo, G, eng, fp8
 
@@ -367,7 +373,7 @@ def main():
     for i in range(args.warmup):
         eng.step(reals[i % 4])
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     # EXACTLY args.steps steps between the barriers; events at the boundaries of (up to) 6 equal windows inside that region
@@ -385,13 +391,13 @@ def main():
             marks[nb].record()
             nb += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_s = e0.elapsed_time(e1) * 1e-3
     t = torch.tensor([max(wall, dev_s)], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     win = sorted(marks[k].elapsed_time(marks[k + 1]) / (bounds[k + 1] - bounds[k]) for k in range(nwin))
@@ -423,8 +429,8 @@ def main():
                                           "SLN/SIREN generator (64 tokens), full alternating G+D step, AdamW"}[args.workload],
                        "fp8_attention": fp8_attn,
                        "per_gpu_batch": B, "global_batch": B * world, "loss": args.loss, "gp_weight": args.gp, "dropout": {"D": eng.p_d, "G": eng.p_g},
-                       "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None, "hip_graph": eng.graph_active,
-                       "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and world > 1, "shard_mapping_update": eng.shard_map,
+                       "parallelism": f"dp{world}", "backend": args.backend if dp else None, "rehearsal": ("one-rank process group: exchange calls executed and captured" if (dp and world == 1) else None), "hip_graph": eng.graph_active,
+                       "hip_graph_fallback": eng.graph_fallback_reason, "compress_mapping_grad": eng.compress_map and dp, "shard_mapping_update": eng.shard_map,
                        "fused_real_fake_pass": not args.no_fuse,
                        "flops_per_image_step": f_step, "flops_executed_per_image_step": f_exec,
                        "pruned": None if args.dense_top_block else "top encoder block behind its attention runs on the CLS rows only (the classifier reads "
@@ -434,7 +440,7 @@ def main():
         }
         # The other single-GPU configurations of BASELINE.json (configs[3], configs[4]: C4 and C5 at B = 128 per GPU, C5 with fp8 attention),
         # timed by the SAME driver-run command: behind the headline's timed region, so the C2 number is untouched.
-        if world == 1 and args.workload == "c2" and not args.no_extra_workloads and args.gp == 0.0:
+        if world == 1 and not dp and args.workload == "c2" and not args.no_extra_workloads and args.gp == 0.0:
             eng.close()
             del eng
             extras = []
@@ -484,7 +490,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 
