@@ -29,6 +29,8 @@ for i in range(N):
         hist.append([round(x, 4) for x in l.tolist()])
     if i % 100 == 0 and first_bad is None and not bool(torch.isfinite(l).all()):
         first_bad = i
+    if i % 5000 == 0 and i:  # (a progress line: a silent run of many minutes looks hung to a job runner)
+        print(f"  step {i}: {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ok = all(torch.isfinite(p).all() for p in list(D.parameters()) + list(G.parameters()))
