@@ -478,13 +478,14 @@ static int vit_backward_impl(const VgVitNet* net, int B, void* ws, const float* 
   const bool drop = dr.thr != 0;
   // dx = gres + LayerNorm'(A W) in one kernel (gemm_row.hip)
   auto row_bwd = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma,
-                     const bf16* gres, bf16* dx, bf16* dxm, float* part, int site, int rows = 0, int drm = 1) -> int {
+                     const bf16* gres, bf16* dx, bf16* dxm, float* part, int site, int rows = 0, int drm = 1, const bf16* gres2 = nullptr) -> int {
     VgRowArgs ra = {};
     ra.N = E;
     ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = rows ? rows : M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
     ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.part = want_wgrad ? part : nullptr; ra.drop_row_mul = drm;  // (no parameter gradients wanted: no column sums)
+    ra.gres2 = gres2;  // the penalty's second backward: the gradient its double backward injected at this LayerNorm's input
     if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
-    const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD, st);
+    const int r = vg_gemm_row_launch(ra, gres2 ? VG_ROW_LNBWD_PEN : VG_ROW_LNBWD, st);
     return r > 0 ? 0 : (r < 0 ? -r : -3);
   };
   VgCtx* ctx = (VgCtx*)net->ctx;
@@ -666,10 +667,11 @@ static int vit_backward_impl(const VgVitNet* net, int B, void* ws, const float* 
     else VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, cur.dz1, M, E, rE, VG_ACT_MUL_Z8, (const bf16*)z1, nullptr, 0.f, st));
     if (inj && inj->s_h) VG_TRY(vg_add_bf16_launch(cur.dz1, inj->s_h + (size_t)l * M * rE, cur.dz1, (long long)M * rE, st));
     const bf16* gres2 = g;  // the residual-stream gradient the norm2 backward adds
-    if (inj && inj->s_xmid) { VG_TRY(vg_add_bf16_launch(g, inj->s_xmid + (size_t)l * ME, inj->tmp, (long long)ME, st)); gres2 = inj->tmp; }
+    const bf16* inj_mid = (inj && inj->s_xmid) ? inj->s_xmid + (size_t)l * ME : nullptr;
+    if (inj_mid && !rown) { VG_TRY(vg_add_bf16_launch(g, inj_mid, inj->tmp, (long long)ME, st)); gres2 = inj->tmp; }  // (the full-row kernel takes it as an operand)
     if (rown) {  // fc1 input gradient + norm2 backward + the residual-stream gradient
       VG_TRY(row_bwd(cur.dz1, rE, wp + po_w1T, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gres2, cur.gmid,
-                     drop ? cur.gm1 : nullptr, part2, 1 + 2 * l));
+                     drop ? cur.gm1 : nullptr, part2, 1 + 2 * l, 0, 1, inj_mid));
     } else {
       VG_TRY(lin_dgrad(cur.dz1, Pb + lo + lay.w1, w.dxn, M, rE, E, 0, nullptr, nullptr, 0.f, st));
       VG_TRY(vg_ln_bwd_launch(w.dxn, xmid, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gres2, cur.gmid, part2, M, E,
@@ -694,10 +696,11 @@ static int vit_backward_impl(const VgVitNet* net, int B, void* ws, const float* 
     if (ctx && want_wgrad && l + 1 <= top && l + 1 >= 0 && (d.L - (l + 1)) >= stage_begin)
       VG_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_side[l + 1], 0));
     const bf16* gres1 = cur.gmid;
-    if (inj && inj->s_x) { VG_TRY(vg_add_bf16_launch(cur.gmid, inj->s_x + (size_t)l * ME, inj->tmp, (long long)ME, st)); gres1 = inj->tmp; }
+    const bf16* inj_x = (inj && inj->s_x) ? inj->s_x + (size_t)l * ME : nullptr;
+    if (inj_x && !rown) { VG_TRY(vg_add_bf16_launch(cur.gmid, inj_x, inj->tmp, (long long)ME, st)); gres1 = inj->tmp; }
     if (rown) {  // QKV input gradient + norm1 backward + the residual-stream gradient
       VG_TRY(row_bwd(cur.dqkv, 3 * E, wp + po_wqkvT, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gres1, nxt.gin,
-                     drop ? nxt.gm2 : nullptr, part1, l > 0 ? 2 + 2 * (l - 1) : 0));
+                     drop ? nxt.gm2 : nullptr, part1, l > 0 ? 2 + 2 * (l - 1) : 0, 0, 1, inj_x));
     } else {
       VG_TRY(vg_ln_bwd_launch(w.dxn, x, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gres1, nxt.gin, part1, M, E,
                               drop ? nxt.gm2 : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
@@ -850,24 +853,34 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
   VG_TRY(vg_ln_bwd_launch(w.dhcls, w.X + (size_t)L * ME, w.meanf, w.rstdf, P + lay.lnf_w, nullptr, w.dxcls, w.part, B, E, nullptr, 0, 0, 1.f, nullptr, st, S));
   VG_TRY(vg_scatter_cls_launch(w.dxcls, q.gin + (size_t)top * ME, B, S, E, st, drop ? q.gm2 + (size_t)top * ME : nullptr, dr.thr, site_key(dr, 2 + 2 * top),
                                dr.scale, dr.step));
+  const long long po_wqkvT = (long long)E * E + (long long)E * rE, po_w1T = po_wqkvT + 3LL * E * E;  // the forward packed these images (carve_vit: wpack)
+  auto pen_row = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma, const bf16* gres,
+                     bf16* dx, bf16* dxm, bf16* dy_out, int site) -> int {
+    VgRowArgs ra = {};
+    ra.N = E; ra.A = A; ra.lda = K; ra.Wp = Wp; ra.M = M; ra.K = K; ra.x = x; ra.mean = mean; ra.rstd = rstd; ra.gamma = gamma;
+    ra.gres = gres; ra.dx = dx; ra.dxm = dxm; ra.dy_out = dy_out; ra.drop_row_mul = 1;  // (part = nullptr: the input gradient only)
+    if (dxm) { ra.drop_thresh = dr.thr; ra.drop_key = site_key(dr, site); ra.drop_scale = dr.scale; ra.drop_step = dr.step; }
+    const int r = vg_gemm_row_launch(ra, VG_ROW_LNBWD_PEN, st);
+    return r > 0 ? 0 : (r < 0 ? -r : -3);
+  };
   for (int l = top; l >= 0; --l) {
     const long long lo = lay.layer0 + (long long)l * lay.layer_stride;
+    const bf16* wp = w.wpack + (size_t)l * lay.layer_weights;
     const bf16* gin = q.gin + (size_t)l * ME;
     const bf16* gb2 = drop ? q.gm2 + (size_t)l * ME : gin;
     bf16 *da1 = q.da1 + (size_t)l * MR, *dz1 = q.dz1 + (size_t)l * MR, *dxn2 = q.dxn2 + (size_t)l * ME, *gmid = q.gmid + (size_t)l * ME;
     bf16 *gm1 = q.gm1 + (size_t)l * ME, *dao = q.dao + (size_t)l * ME, *dqkv = q.dqkv + (size_t)l * ME * 3, *dxn1 = q.dxn1 + (size_t)l * ME;
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, da1, M, E, rE, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, nullptr, dz1, nullptr, (long long)MR, 1, 1, st));
-    VG_TRY(lin_dgrad(dz1, Pb + lo + lay.w1, dxn2, M, rE, E, 0, nullptr, nullptr, 0.f, st));
-    VG_TRY(vg_ln_bwd_launch(dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid, w.part, M, E,
-                            drop ? gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    // fc1 input gradient + norm2 backward in the full-row kernel, which here also WRITES the GEMM result (the double backward's d xn2)
+    VG_TRY(pen_row(dz1, rE, wp + po_w1T, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid,
+                   drop ? gm1 : nullptr, dxn2, 1 + 2 * l));
     VG_TRY(lin_dgrad(drop ? gm1 : gmid, Pb + lo + lay.wo, dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(w.qkv + (size_t)l * ME * 3, w.ao + (size_t)l * ME, dao, w.lse + (size_t)l * B * d.H * S, dqkv, B, d.H, S, HE, scale, 0, st));
-    VG_TRY(lin_dgrad(dqkv, Pb + lo + lay.wqkv, dxn1, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
     bf16* gx = l > 0 ? q.gin + (size_t)(l - 1) * ME : q.g0;
     bf16* gxm = l > 0 ? q.gm2 + (size_t)(l - 1) * ME : q.g0m;
-    VG_TRY(vg_ln_bwd_launch(dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx, w.part, M, E,
-                            drop ? gxm : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+    VG_TRY(pen_row(dqkv, 3 * E, wp + po_wqkvT, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx,
+                   drop ? gxm : nullptr, dxn1, l > 0 ? 2 + 2 * (l - 1) : 0));
   }
   VG_TRY(vg_take_rows_launch(drop ? q.g0m : q.g0, w.gp, B, S, 1, NP, E, st));
   VG_TRY(lin_dgrad(w.gp, Pb + lay.conv_w, w.dA, B * NP, E, Kp, 0, nullptr, nullptr, 0.f, st));  // = the image gradient, patch by patch

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
   // N = 512, forward: gamma / beta live behind the ring too - 64 registers of them on top of 4 chunks of residual, modulation and row values
   // spilled 92 registers in the self-modulated form
   constexpr bool GB_LDS = N > 384;
-  if (EPI == VG_ROW_LNBWD && tid < RW_E / 4) {  // visible to everyone behind the first tile's barriers
+  constexpr bool PEN = (EPI == VG_ROW_LNBWD_PEN);  // the gradient penalty's variant of the LayerNorm-backward epilogue: + gres2, + dy_out
+  if (EPI != VG_ROW_LNFWD && tid < RW_E / 4) {  // visible to everyone behind the first tile's barriers
     *(f32x4*)(smem + RW_BODY + 16 * tid) = *(const f32x4*)(a.gamma + 4 * tid);
     if (SLN) *(f32x4*)(smem + RW_BODY + RW_E * 4 + 16 * tid) = *(const f32x4*)(a.lbias + 4 * tid);
   }
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     asm volatile("" : "+s"(e.bias), "+s"(e.res), "+s"(e.Y), "+s"(e.Yn), "+s"(e.mean_out), "+s"(e.rstd_out), "+s"(e.beta), "+s"(e.gamma));
     asm volatile("" : "+s"(e.x), "+s"(e.mean), "+s"(e.rstd), "+s"(e.gres), "+s"(e.dx), "+s"(e.dxm));
     asm volatile("" : "+s"(e.wmod), "+s"(e.gs), "+s"(e.bs), "+s"(e.dw_acc), "+s"(e.resf));
+    if (PEN) asm volatile("" : "+s"(e.gres2), "+s"(e.dy_out));
     const float g_s = SLN ? e.gs[0] : 1.f, b_s = SLN ? e.bs[0] : 0.f;
     if (EPI == VG_ROW_LNFWD) {
       // LNFWD keeps the sum in fp32 until the residual is added (ONE rounding, as the unfused epilogue had): fp32 tile rows of
@@ -446,18 +448,24 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
           const int rl = RPP * ps + RPW * wid + rgl;
           const size_t row = (size_t)(m0 + rl);
           chunk_t gr[CPL];  // the residual-stream gradient is only needed behind the row sums: its latency sits under them
+          chunk_t gr2[PEN ? CPL : 1];
           chunk_t wm[SLN ? CPL : 1];
 #pragma unroll
           for (int i = 0; i < CPL; ++i) {
             if (SLN) wm[SLN ? i : 0] = *(const chunk_t*)(e.wmod + row * RW_E + CH * (subl + LPR * i));
             gr[i] = zero_chunk();
             if (e.gres && !RW_DBG(16)) gr[i] = *(const chunk_t*)(e.gres + row * RW_E + CH * (subl + LPR * i));
+            if (PEN) {
+              gr2[PEN ? i : 0] = zero_chunk();
+              if (e.gres2) gr2[PEN ? i : 0] = *(const chunk_t*)(e.gres2 + row * RW_E + CH * (subl + LPR * i));
+            }
           }
           float xh[CPL][CH], gg[CPL][CH];
           float c1 = 0.f, c2 = 0.f;
 #pragma unroll
           for (int i = 0; i < CPL; ++i) {
             const chunk_t t = *(const chunk_t*)(smem + rl * RW_TS + 2 * CH * (subl + LPR * i));
+            if (PEN) { if (e.dy_out) *(chunk_t*)(e.dy_out + row * RW_E + CH * (subl + LPR * i)) = t; }  // A W as the unfused pair stored it (bf16)
             float gm[CH], lb[SLN ? CH : 1], dwv[SLN ? CH : 1];
             ld_f32(gam_lds, i, gm);
             if (SLN) {
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
             const int c = CH * (subl + LPR * i);
             chunk_t o;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), vg_bf2f(gr[i][j])));
+            for (int j = 0; j < CH; ++j) o[j] = vg_f2bf(fmaf(rs, fmaf(-xh[i][j], c2, gg[i][j] - c1), PEN ? vg_bf2f(gr[i][j]) + vg_bf2f(gr2[PEN ? i : 0][j]) : vg_bf2f(gr[i][j])));
             if (!RW_DBG(8)) *(chunk_t*)(e.dx + row * RW_E + c) = o;
             if (e.dxm) {  // gradient entering the dropped branch: the mask the forward epilogue applied
               const unsigned i4 = ((unsigned)row * drm * (unsigned)RW_E + (unsigned)c) >> 2;
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void vg_gemm_row_kernel(const VgRowArgs a) 
     }
     n -= mt; m0 += 16 * mt; first = false;
   }
-  if (EPI == VG_ROW_LNBWD && a.part) {
+  if (EPI != VG_ROW_LNFWD && a.part) {
     float* out = a.part + (size_t)blockIdx.x * a.part_w;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -678,6 +686,8 @@ static int rw_launch(VgRowArgs a, int epi, hipStream_t st) {
   if (epi == VG_ROW_LNFWD) {
     if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, true, N>), dim3(nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNFWD, false, N>), dim3(nwg), dim3(512), 0, st, a);
+  } else if (epi == VG_ROW_LNBWD_PEN) {
+    hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD_PEN, false, N>), dim3(nwg), dim3(512), 0, st, a);
   } else {
     if (sln) hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, true, N>), dim3(nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vg_gemm_row_kernel<VG_ROW_LNBWD, false, N>), dim3(nwg), dim3(512), 0, st, a);
@@ -703,8 +713,9 @@ int vg_gemm_row_launch(VgRowArgs a, int epi, hipStream_t st) {
   if (epi == VG_ROW_LNFWD) {
     if (!a.Y || (a.Yn && (!a.mean_out || !a.rstd_out || !a.gamma || !a.beta)) || (sln && !a.Yn)) return -1;
     if (a.resf && (a.res || a.res_period < 1)) return -1;
-  } else if (epi == VG_ROW_LNBWD) {
+  } else if (epi == VG_ROW_LNBWD || epi == VG_ROW_LNBWD_PEN) {
     if (!a.x || !a.mean || !a.rstd || !a.gamma || !a.dx || (sln && (!a.part || !a.lbias || !a.dw_acc))) return -1;  // part == nullptr: no column sums (input gradient only)
+    if (epi == VG_ROW_LNBWD_PEN && sln) return -4;
     a.part_w = 3 * RW_E + (sln ? 64 : 0);
   } else {
     return -4;

@@ -6,7 +6,7 @@
 #define VG_ROW_N 384  // default output width of a full-row problem (the embedding width of the C1-C3 configurations); 512 (C4) since round 4
 int vg_row_width_ok(int N);  // widths the kernel is built for: 384, 512
 
-enum { VG_ROW_LNFWD = 0, VG_ROW_LNBWD = 1 };
+enum { VG_ROW_LNFWD = 0, VG_ROW_LNBWD = 1, VG_ROW_LNBWD_PEN = 2 };  // 2: LNBWD with the gradient penalty's two extra operands (plain LayerNorm only; separate instantiation)
 
 struct VgRowArgs {
   const bf16* A; int lda;  // [M, K] row-major
@@ -29,6 +29,8 @@ struct VgRowArgs {
   const float* mean; const float* rstd;  // [M]
   const bf16* gres;        // [M, 384] gradient arriving over the residual connection (nullable)
   bf16* dx; bf16* dxm;     // [M, 384]; dxm nullable
+  const bf16* gres2;       // VG_ROW_LNBWD_PEN: [M, 384] a second gradient added to dx (what the double backward injected at the LayerNorm's input; nullable)
+  bf16* dy_out;            // VG_ROW_LNBWD_PEN: [M, 384] receives A W itself, the LayerNorm backward's dY (the double backward's operand; nullable)
   float* part;             // [nwg][3*384]: per workgroup column sums  d gamma | d beta | colsum(dxm ? dxm : dx); nullptr (plain LayerNorm
                            // only): no sums at all - a backward that wants the input gradient alone (the generator's pass through D)
   // ---- self-modulated LayerNorm (v1 generator, src/v1/spectral_layer_norm.py:19-20): wmod != nullptr -------------------------
