@@ -266,21 +266,35 @@ def _penalty_c_call(D, real, fake, eps, weight, p_drop=0.0, seed=11, step=None):
     return float(out), fl.grad.detach().clone()
 
 
-@pytest.mark.parametrize("B,layers", [(16, 2), (32, 3), (256, 6)])
-def test_penalty_c_call_matches_the_operator_set(B, layers):
+@pytest.mark.parametrize("B,layers,geo", [(16, 2, "c2"), (32, 3, "c2"), (256, 6, "c2"), (16, 2, "c4"), (16, 2, "c2-10-classes"), (48, 1, "c2-mlp4")])
+def test_penalty_c_call_matches_the_operator_set(B, layers, geo):
     """vg_vit_penalty (forward, input-gradient backward, its double backward and the second backward as ONE C call) against the
     operator-set form through torch autograd (penalty.gradient_penalty, itself pinned to the reference's fixture above): dropout off,
     the same epsilon.  Both are bf16 pipelines with different fusion (the C call's second backward runs the fused full-row kernels):
     per tensor within 2^-6 of max|.|, the penalty within 2^-7."""
     from vit_gan_amd import ops2
     from vit_gan_amd.penalty import gradient_penalty
-    from test_engine_gpu import _build
-    D, _, _ = _build(B, "wasserstein", layers=layers)
+    from vit_gan_amd.config import Config
+    from vit_gan_amd.modules import ViTDiscriminator
+    # c2: 32 x 32, patch 4, E = 384, 4 heads; c4: BASELINE configs[3]'s geometry (64 x 64, patch 8, E = 512, 8 heads of 64: the N = 512
+    # instantiation of the full-row kernels and of their penalty variant); 10 classes: the classifier's second-order kernel with more than
+    # one logit; mlp4: forward_mul 4
+    kw = dict(embeddings_dimension=384, classes_count=1, dropout_rate=0.0, batch_size=B, transformer_blocks_count=layers)
+    img = 32
+    if geo == "c4":
+        kw.update(embeddings_dimension=512, attention_heads_count=8, patch_size=8, image_size=64)
+        img = 64
+    elif geo == "c2-10-classes":
+        kw.update(classes_count=10)
+    elif geo == "c2-mlp4":
+        kw.update(mlp_ratio=4)
+    torch.manual_seed(3)
+    D = ViTDiscriminator(Config(**kw)).cuda()
     D.train()
     fl = D.vit._flat
     g = torch.Generator().manual_seed(B)
-    real = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
-    fake = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
+    real = (torch.rand(B, 3, img, img, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
+    fake = (torch.rand(B, 3, img, img, generator=g) * 2 - 1).cuda().to(torch.bfloat16).float()
     eps = torch.rand(B, 1, 1, 1, generator=g).cuda()
     w = 10.0
     fl.attach_grads()
