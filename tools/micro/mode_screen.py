@@ -20,6 +20,10 @@ MODES = {
     "hinge": dict(loss="hinge"),
     "wasserstein + clipping + diversity + instance noise": dict(loss="wasserstein", clip_d=5.0, clip_g=0.5, diversity_weight=0.1, instance_noise=0.1),
     "wasserstein + gp (C call) + instance noise": dict(loss="wasserstein", clip_d=5.0, clip_g=0.5, gp_weight=10.0, instance_noise=0.1),
+    "wasserstein + gp (C call), unfused real / fake": dict(loss="wasserstein", gp_weight=10.0, fuse_real_fake=False),
+    "wasserstein + gp (C call), weight gradients on a side stream": dict(loss="wasserstein", gp_weight=10.0, concurrent_wgrad=True),
+    "wasserstein + gp (C call), dense top block, no dropout": dict(loss="wasserstein", gp_weight=10.0, dense_top_block=True, d_dropout=0.0, g_dropout=0.0),
+    "wasserstein + gp (operator set)": dict(loss="wasserstein", gp_weight=10.0, gp_autograd=True),
     "dense top block": dict(dense_top_block=True),
     "no dropout": dict(d_dropout=0.0, g_dropout=0.0),
 }
