@@ -379,9 +379,9 @@ int vg_vit_backward_stages(const VgVitNet* net, int B, void* ws, const float* dl
  *   *penalty_out = penalty (device float).  real / fake: bf16 [B, C, IH, IH]; eps: device fp32 [B] (the reference draws torch.rand).
  * ws: a vg_vit_ws_bytes(d, B) workspace (the call runs its own forward in it); ws_pen: vg_vit_penalty_ws_bytes(d, B) bytes.
  * The discriminator runs in train mode like the reference's does: net->dropout_p / dropout_seed / dropout_step give the masks (one set
- * for all passes of the call).  net->dense_top and net->ctx are ignored (every row of the top block; one stream).  -3: shapes the
- * full-row kernels do not take (E other than 384 / 512, B * tokens not a multiple of 16) or attn_fp8 - callers fall back to the
- * operator set there. */
+ * for all passes of the call).  net->dense_top and net->ctx are ignored (every row of the top block; one stream).  Every network
+ * vg_vit_layout accepts; where the full-row kernels take the shape (E = 384 / 512, B * tokens a multiple of 16) the input gradients +
+ * LayerNorm backwards are fused.  -3: attn_fp8 (the second-order attention kernel differentiates the bf16 one), B * E not a multiple of 8. */
 long long vg_vit_penalty_ws_bytes(const VgVitDims* d, int B);
 int vg_vit_penalty(const VgVitNet* net, int B, const void* real, const void* fake, const float* eps, float weight, void* ws, void* ws_pen,
                    float* penalty_out, void* stream);

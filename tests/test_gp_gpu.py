@@ -141,18 +141,19 @@ def test_gradient_penalty_matches_the_reference_fixture():
         u.assert_close(got[k], torch.from_numpy(npz[f"full/{k}"]), 2.0 ** -4, f"{k} vs the reference fixture", floor=1e-5)
 
 
-@pytest.mark.parametrize("B", [8, 16])
-def test_engine_step_with_gradient_penalty(B):
+@pytest.mark.parametrize("B,autograd", [(8, False), (16, False), (8, True)])
+def test_engine_step_with_gradient_penalty(B, autograd):
     """The reference's Wasserstein discriminator step with the penalty (training.py:83-106: critic loss + lambda_gp * gp,
-    clipping) through GanEngine vs the step oracle, same noise and the same epsilon.  B = 16: the penalty as one C call
-    (vg_vit_penalty; 16 x 65 rows are whole units of 16); B = 8: the operator set through autograd."""
+    clipping) through GanEngine vs the step oracle, same noise and the same epsilon.  The penalty as one C call
+    (vg_vit_penalty) - B = 16: 16 x 65 rows are whole units of 16, the fused full-row forms; B = 8: the GEMM + LayerNorm pairs -
+    and, gp_autograd=True, as the operator set through autograd."""
     from vit_gan_amd.engine import GanEngine
     from test_engine_gpu import _build
     D, G, oracle = _build(B, "wasserstein")
     oracle.gp_weight = 10.0
     oracle.clip_d = 5.0
-    eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True)
-    assert eng.gp_c_call == (B == 16)
+    eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True, gp_autograd=autograd)
+    assert eng.gp_c_call == (not autograd)
     g = torch.Generator().manual_seed(0)
     real = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
     z = torch.randn(B, 1024, generator=g)
@@ -175,11 +176,12 @@ def test_engine_step_with_gradient_penalty(B):
         GanEngine(D, G, batch=B, gp_weight=1.0, two_stream=True)
 
 
-@pytest.mark.parametrize("B,p_drop", [(8, 0.0), (16, 0.0), (16, 0.1)])
-def test_engine_step_with_gradient_penalty_replays_as_a_graph(B, p_drop):
+@pytest.mark.parametrize("B,p_drop,autograd", [(8, 0.0, True), (8, 0.1, False), (16, 0.0, False), (16, 0.1, False)])
+def test_engine_step_with_gradient_penalty_replays_as_a_graph(B, p_drop, autograd):
     """The penalty's passes captured in the step's hipGraph: three replayed steps equal three eager steps bit for bit, and the capture
-    really is active.  B = 8: the autograd passes of the operator set (dropout off and epsilon fixed: the only randomness of that pass
-    is torch's); B = 16: the C call, also with dropout - its masks are the engine's counter-based ones, a function of the step counter."""
+    really is active.  autograd: the autograd passes of the operator set (dropout off and epsilon fixed: the only randomness of that pass
+    is torch's); else the C call (B = 8: its unfused forms), also with dropout - its masks are the engine's counter-based ones, a function
+    of the step counter."""
     from vit_gan_amd.engine import GanEngine
     from test_engine_gpu import _build
     g = torch.Generator().manual_seed(0)
@@ -190,8 +192,8 @@ def test_engine_step_with_gradient_penalty_replays_as_a_graph(B, p_drop):
     for use_graph in (False, True):
         D, G, _ = _build(B, "wasserstein")
         eng = GanEngine(D, G, batch=B, loss="wasserstein", gp_weight=10.0, clip_d=5.0, external_noise=True, use_graph=use_graph,
-                        d_dropout=p_drop, g_dropout=p_drop)
-        assert eng.gp_c_call == (B == 16)
+                        d_dropout=p_drop, g_dropout=p_drop, gp_autograd=autograd)
+        assert eng.gp_c_call == (not autograd)
         eng.gp_epsilon = eps
         ls = [eng.step(r, z).clone() for r, z in zip(reals, zs)]
         torch.cuda.synchronize()
@@ -266,7 +268,8 @@ def _penalty_c_call(D, real, fake, eps, weight, p_drop=0.0, seed=11, step=None):
     return float(out), fl.grad.detach().clone()
 
 
-@pytest.mark.parametrize("B,layers,geo", [(16, 2, "c2"), (32, 3, "c2"), (256, 6, "c2"), (16, 2, "c4"), (16, 2, "c2-10-classes"), (48, 1, "c2-mlp4")])
+@pytest.mark.parametrize("B,layers,geo", [(16, 2, "c2"), (32, 3, "c2"), (256, 6, "c2"), (16, 2, "c4"), (16, 2, "c2-10-classes"), (48, 1, "c2-mlp4"),
+                                          (8, 2, "c2"), (8, 2, "e128"), (8, 1, "c5")])
 def test_penalty_c_call_matches_the_operator_set(B, layers, geo):
     """vg_vit_penalty (forward, input-gradient backward, its double backward and the second backward as ONE C call) against the
     operator-set form through torch autograd (penalty.gradient_penalty, itself pinned to the reference's fixture above): dropout off,
@@ -288,6 +291,11 @@ def test_penalty_c_call_matches_the_operator_set(B, layers, geo):
         kw.update(classes_count=10)
     elif geo == "c2-mlp4":
         kw.update(mlp_ratio=4)
+    elif geo == "e128":    # no full-row kernel at this width: the GEMM + LayerNorm pairs (B = 8 at c2: rows not whole units of 16 - the same)
+        kw.update(embeddings_dimension=128, attention_heads_count=4)
+    elif geo == "c5":      # BASELINE configs[4]'s geometry with bf16 attention: 128 x 128, patch 16, E = 768, 12 heads
+        kw.update(embeddings_dimension=768, attention_heads_count=12, patch_size=16, image_size=128)
+        img = 128
     torch.manual_seed(3)
     D = ViTDiscriminator(Config(**kw)).cuda()
     D.train()

@@ -809,11 +809,12 @@ static long long carve_pen(const VgVitDims& d, int B, void* base, PenWs& q) {
   q.s_xcls = c.take<bf16>(B * E); q.tmp = c.take<bf16>(M * E);
   return c.off;
 }
-// The penalty needs the full-row kernels' shapes (E = 384 or 512, rows in whole units of 16) and bf16 attention; -3 otherwise
+// Every network the plain step trains in bf16 (E a multiple of 128: the alignment of the elementwise kernels follows); where the full-row
+// kernels take the shape (E = 384 / 512, rows in whole units of 16) the input gradients and LayerNorm backwards of passes 2 and 5 are fused,
+// elsewhere they are the GEMM + LayerNorm pairs.  -3: fp8 attention (the second-order attention kernel differentiates the bf16 one).
 static int pen_shape_ok(const VgVitNet* net, int B) {
   const VgVitDims& d = net->d;
-  const int S = (d.IH / d.P) * (d.IH / d.P) + 1;
-  return !net->attn_fp8 && vit_row_nwg(d, B * S) > 0 && (B * d.E) % 8 == 0 && ((long long)d.C * d.IH * d.IH) % 4 == 0;
+  return !net->attn_fp8 && ((long long)B * d.E) % 8 == 0 && ((long long)d.C * d.IH * d.IH) % 4 == 0 && ((long long)d.C * d.P * d.P) % 4 == 0;
 }
 extern "C" long long vg_vit_penalty_ws_bytes(const VgVitDims* d, int B) {
   VgVitLayout lay;
@@ -854,6 +855,7 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
   VG_TRY(vg_scatter_cls_launch(w.dxcls, q.gin + (size_t)top * ME, B, S, E, st, drop ? q.gm2 + (size_t)top * ME : nullptr, dr.thr, site_key(dr, 2 + 2 * top),
                                dr.scale, dr.step));
   const long long po_wqkvT = (long long)E * E + (long long)E * rE, po_w1T = po_wqkvT + 3LL * E * E;  // the forward packed these images (carve_vit: wpack)
+  const int rown = vit_row_nwg(d, M);  // 0: no full-row kernel for this shape - the unfused pairs
   auto pen_row = [&](const bf16* A, int K, const bf16* Wp, const bf16* x, const float* mean, const float* rstd, const float* gamma, const bf16* gres,
                      bf16* dx, bf16* dxm, bf16* dy_out, int site) -> int {
     VgRowArgs ra = {};
@@ -873,14 +875,26 @@ extern "C" int vg_vit_penalty(const VgVitNet* net0, int B, const void* real, con
     VG_TRY(lin_dgrad(gb2, Pb + lo + lay.w2, da1, M, E, rE, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_act2_launch(q.h + (size_t)l * MR, da1, nullptr, dz1, nullptr, (long long)MR, 1, 1, st));
     // fc1 input gradient + norm2 backward in the full-row kernel, which here also WRITES the GEMM result (the double backward's d xn2)
-    VG_TRY(pen_row(dz1, rE, wp + po_w1T, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid,
-                   drop ? gm1 : nullptr, dxn2, 1 + 2 * l));
+    if (rown) {
+      VG_TRY(pen_row(dz1, rE, wp + po_w1T, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid,
+                     drop ? gm1 : nullptr, dxn2, 1 + 2 * l));
+    } else {
+      VG_TRY(lin_dgrad(dz1, Pb + lo + lay.w1, dxn2, M, rE, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_ln_bwd_launch(dxn2, w.xmid + (size_t)l * ME, w.mean2 + (size_t)l * M, w.rstd2 + (size_t)l * M, P + lo + lay.ln2_w, gin, gmid, w.part, M, E,
+                              drop ? gm1 : nullptr, dr.thr, site_key(dr, 1 + 2 * l), dr.scale, dr.step, st));
+    }
     VG_TRY(lin_dgrad(drop ? gm1 : gmid, Pb + lo + lay.wo, dao, M, E, E, 0, nullptr, nullptr, 0.f, st));
     VG_TRY(vg_attn_bwd_launch(w.qkv + (size_t)l * ME * 3, w.ao + (size_t)l * ME, dao, w.lse + (size_t)l * B * d.H * S, dqkv, B, d.H, S, HE, scale, 0, st));
     bf16* gx = l > 0 ? q.gin + (size_t)(l - 1) * ME : q.g0;
     bf16* gxm = l > 0 ? q.gm2 + (size_t)(l - 1) * ME : q.g0m;
-    VG_TRY(pen_row(dqkv, 3 * E, wp + po_wqkvT, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx,
-                   drop ? gxm : nullptr, dxn1, l > 0 ? 2 + 2 * (l - 1) : 0));
+    if (rown) {
+      VG_TRY(pen_row(dqkv, 3 * E, wp + po_wqkvT, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx,
+                     drop ? gxm : nullptr, dxn1, l > 0 ? 2 + 2 * (l - 1) : 0));
+    } else {
+      VG_TRY(lin_dgrad(dqkv, Pb + lo + lay.wqkv, dxn1, M, 3 * E, E, 0, nullptr, nullptr, 0.f, st));
+      VG_TRY(vg_ln_bwd_launch(dxn1, w.X + (size_t)l * ME, w.mean1 + (size_t)l * M, w.rstd1 + (size_t)l * M, P + lo + lay.ln1_w, gmid, gx, w.part, M, E,
+                              drop ? gxm : nullptr, dr.thr, site_key(dr, l > 0 ? 2 + 2 * (l - 1) : 0), dr.scale, dr.step, st));
+    }
   }
   VG_TRY(vg_take_rows_launch(drop ? q.g0m : q.g0, w.gp, B, S, 1, NP, E, st));
   VG_TRY(lin_dgrad(w.gp, Pb + lay.conv_w, w.dA, B * NP, E, Kp, 0, nullptr, nullptr, 0.f, st));  // = the image gradient, patch by patch

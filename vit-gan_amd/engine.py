@@ -61,11 +61,11 @@ class GanEngine:
         two chains are in different phases (a GEMM main loop next to another GEMM's epilogue, a LayerNorm next to a
         GEMM), which the single-chain step cannot be: every launch of this model covers the chip about once.
         gp_weight: weight of the WGAN-GP gradient penalty in the discriminator loss (``c.lambda_gp`` of training.py:106; the
-        field is missing from the reference's Config).  Where the full-row kernels take the network (E 384 / 512, B * tokens a
-        multiple of 16, bf16 attention) the penalty is ONE C call, ``vg_vit_penalty``: forward, input-gradient backward, its
-        double backward and the second backward as kernel sequences with the engine's counter-based dropout masks (the
-        discriminator is in train mode there, as in the reference); ``gp_autograd=True`` - and every other shape - takes the
-        operator-set path below, the form the C call is tested against.  That path runs through torch autograd over the twice-
+        field is missing from the reference's Config).  The penalty is ONE C call, ``vg_vit_penalty``: forward, input-gradient
+        backward, its double backward and the second backward as kernel sequences with the engine's counter-based dropout masks
+        (the discriminator is in train mode there, as in the reference; the input gradients + LayerNorm backwards are fused where
+        the full-row kernels take the shape); ``gp_autograd=True`` takes the operator-set path below, the form the C call is
+        tested against.  That path runs through torch autograd over the twice-
         differentiable operator set (penalty.py) on the discriminator's real / fake inputs of this step and accumulates
         into the same gradient buffer before the exchange and AdamW.  With ``use_graph`` the autograd passes are captured with
         the rest of the step (every operator is an enqueue-only kernel call; epsilon and the penalty pass's dropout masks come
@@ -124,10 +124,7 @@ class GanEngine:
             # the penalty path (ops2.py) differentiates the bf16 attention kernels: with fp8 operands in the trained network
             # it would penalise a slightly different function than the one being trained
             raise ValueError("gp_weight: the gradient penalty is built on the bf16 attention kernels; switch attention_fp8 off")
-        d_ = vit._dims
-        tokens = (d_.IH // d_.P) ** 2 + 1
-        self.gp_c_call = (self.gp_w != 0.0 and not gp_autograd and d_.E in (384, 512) and (int(batch) * tokens) % 16 == 0
-                          and not bool(getattr(vit, "attention_fp8", False)))
+        self.gp_c_call = self.gp_w != 0.0 and not gp_autograd and not bool(getattr(vit, "attention_fp8", False))
         self.div_w = float(diversity_weight)
         self.inst_sigma = float(instance_noise)
         self.external_noise = bool(external_noise)
