@@ -329,14 +329,14 @@ def test_penalty_c_call_matches_the_operator_set(B, layers, geo):
     assert not bad, bad
 
 
-def test_penalty_c_call_with_dropout_is_the_gradient_of_its_own_value():
+@pytest.mark.parametrize("B,layers", [(16, 2), (256, 6)])
+def test_penalty_c_call_with_dropout_is_the_gradient_of_its_own_value(B, layers):
     """Train-mode dropout (the reference's discriminator is in train mode inside gradient_penalty): the five passes of the call must draw
     the same masks.  A mask mismatch between any two passes leaves the value fine and the gradient wrong, so: the directional derivative
     of the call's penalty VALUE along its own gradient, by central differences on the fp32 master weights (same seed and step counter =
     same masks), against |gradient|^2."""
     from test_engine_gpu import _build
-    B = 16
-    D, _, _ = _build(B, "wasserstein", layers=2)
+    D, _, _ = _build(B, "wasserstein", layers=layers)   # (256, 6): the benchmarked configuration
     D.train()
     fl = D.vit._flat
     g = torch.Generator().manual_seed(5)
